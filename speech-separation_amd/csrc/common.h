@@ -1,0 +1,78 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) DTTNet kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+struct bf16 { unsigned short x; };          // raw bfloat16 storage
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16* p) { return bf2f(p->x); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16* p, float v) { p->x = f2bf(v); }
+
+// 16-byte vector of T: 4 floats or 8 bf16
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    float4 v;
+    __device__ __forceinline__ float get(int i) const { return (&v.x)[i]; }
+    __device__ __forceinline__ void set(int i, float f) { (&v.x)[i] = f; }
+};
+template <> struct Vec16<bf16> {
+    static constexpr int N = 8;
+    uint4 v;
+    __device__ __forceinline__ float get(int i) const {
+        uint32_t w = (&v.x)[i >> 1];
+        return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+    }
+    __device__ __forceinline__ void set(int i, float f) {
+        uint32_t b = f2bf(f);
+        uint32_t& w = (&v.x)[i >> 1];
+        w = (i & 1) ? ((w & 0x0000ffffu) | (b << 16)) : ((w & 0xffff0000u) | b);
+    }
+};
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& r) {
+    *reinterpret_cast<decltype(r.v)*>(p) = r.v;
+}
+template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
+    Vec16<T> r;
+    r.v.x = 0; r.v.y = 0; r.v.z = 0; r.v.w = 0;
+    return r;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Host side error plumbing (api.cpp)
+extern "C" const char* dtt_last_error();
+void dtt_set_error(const char* fmt, ...);
+#define DTT_CHECK(cond, ...) do { if (!(cond)) { dtt_set_error(__VA_ARGS__); return -1; } } while (0)
+#define DTT_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
+    dtt_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); return -2; } } while (0)

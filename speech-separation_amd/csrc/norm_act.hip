@@ -1,0 +1,441 @@
+// InstanceNorm2d(affine=False)+GELU and GroupNorm kernels on channels-last
+// tensors, forward and backward.  HBM-bound: 16-byte vector accesses, two-stage
+// deterministic reductions (no float atomics).
+#include "common.h"
+#include "../../include/dtt_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---- block-level helper: reduce per-thread EPT-vectors over the threads that own
+// the same channel chunk (tid % cpp), result per channel in `out[C]` (LDS).
+template <int EPT>
+__device__ __forceinline__ void reduce_channels(const float (&v)[EPT], float* red, float* out, int cpp, int nact,
+                                                int C) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) red[tid * EPT + e] = (tid < nact) ? v[e] : 0.f;
+    __syncthreads();
+    for (int c = tid; c < C; c += NT) {
+        int cq = c / EPT, e = c % EPT;
+        float s = 0.f;
+        for (int t = cq; t < nact; t += cpp) s += red[t * EPT + e];
+        out[c] = s;
+    }
+    __syncthreads();
+}
+
+// =================== InstanceNorm statistics ===================
+// y: [B][P][C]; chunk of pixels per block; partial[b][chunk][C][2] = {mean, M2}
+template <typename T>
+__global__ __launch_bounds__(NT) void in_stats_partial(const T* __restrict__ y, float* __restrict__ partial, int P,
+                                                       int C, int chunk) {
+    constexpr int EPT = Vec16<T>::N;
+    extern __shared__ float sm[];
+    float* red = sm;                 // NT*EPT
+    float* chv = sm + NT * EPT;      // C
+    const int cpp = C / EPT, ppi = NT / cpp, nact = ppi * cpp;
+    const int tid = threadIdx.x, pl = tid / cpp, cq = tid % cpp;
+    const int b = blockIdx.y, ck = blockIdx.x;
+    const int p0 = ck * chunk, p1 = min(P, p0 + chunk);
+    const T* base = y + ((int64_t)b * P) * C + cq * EPT;
+    float acc[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
+    if (tid < nact)
+        for (int p = p0 + pl; p < p1; p += ppi) {
+            Vec16<T> v = ld16<T>(base + (int64_t)p * C);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) acc[e] += v.get(e);
+        }
+    reduce_channels<EPT>(acc, red, chv, cpp, nact, C);
+    const float inv = 1.f / (float)(p1 - p0);
+    float mean[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { mean[e] = chv[cq * EPT + e] * inv; acc[e] = 0.f; }
+    if (tid < nact)
+        for (int p = p0 + pl; p < p1; p += ppi) {
+            Vec16<T> v = ld16<T>(base + (int64_t)p * C);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) { float d = v.get(e) - mean[e]; acc[e] += d * d; }
+        }
+    float* dst = partial + (((int64_t)b * gridDim.x + ck) * C) * 2;
+    if (tid < cpp)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) dst[(cq * EPT + e) * 2] = mean[e];
+    reduce_channels<EPT>(acc, red, chv, cpp, nact, C);
+    for (int c = tid; c < C; c += NT) dst[c * 2 + 1] = chv[c];
+}
+
+// merge chunk partials (Chan et al.) -> stats[b][c] = {mean, rstd}
+__global__ void in_stats_finalize(const float* __restrict__ partial, float* __restrict__ stats, int P, int C,
+                                  int chunk, int nchunks, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+        const float* s = partial + (((int64_t)b * nchunks + k) * C + c) * 2;
+        float nb = (float)(min(P, (k + 1) * chunk) - k * chunk);
+        float d = s[0] - mean, nn = n + nb;
+        mean += d * nb / nn;
+        m2 += s[1] + d * d * n * nb / nn;
+        n = nn;
+    }
+    stats[((int64_t)b * C + c) * 2] = mean;
+    stats[((int64_t)b * C + c) * 2 + 1] = rsqrtf(m2 / n + eps);
+}
+
+// z[b][fz][tz][c] = gelu((y[b][f][t][c]-mean)*rstd), cropping (Fy,Ty) -> (Fz,Tz)
+template <typename T>
+__global__ __launch_bounds__(NT) void in_gelu_fwd(const T* __restrict__ y, const float* __restrict__ stats,
+                                                  T* __restrict__ z, int B, int Fy, int Ty, int Fz, int Tz, int C) {
+    constexpr int EPT = Vec16<T>::N;
+    const int cpp = C / EPT;
+    const int64_t total = (int64_t)B * Fz * Tz * cpp;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int cq = (int)(i % cpp);
+        int64_t pix = i / cpp;
+        int t = (int)(pix % Tz);
+        int64_t r = pix / Tz;
+        int f = (int)(r % Fz), b = (int)(r / Fz);
+        Vec16<T> v = ld16<T>(y + (((int64_t)b * Fy + f) * Ty + t) * C + cq * EPT);
+        const float* s = stats + ((int64_t)b * C + cq * EPT) * 2;
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) o.set(e, gelu_f((v.get(e) - s[2 * e]) * s[2 * e + 1]));
+        st16<T>(z + pix * C + cq * EPT, o);
+    }
+}
+
+// backward pass 1: partial[b][chunk][C][2] = {sum dyh, sum dyh*yh} over the FULL (Fy,Ty) plane,
+// dz is zero outside the (Fz,Tz) crop.
+template <typename T>
+__global__ __launch_bounds__(NT) void in_gelu_bwd_partial(const T* __restrict__ y, const T* __restrict__ dz,
+                                                          const float* __restrict__ stats,
+                                                          float* __restrict__ partial, int Fy, int Ty, int Fz,
+                                                          int Tz, int C, int chunk) {
+    constexpr int EPT = Vec16<T>::N;
+    extern __shared__ float sm[];
+    float* red = sm;
+    float* chv = sm + NT * EPT;
+    const int cpp = C / EPT, ppi = NT / cpp, nact = ppi * cpp;
+    const int tid = threadIdx.x, pl = tid / cpp, cq = tid % cpp;
+    const int b = blockIdx.y, ck = blockIdx.x, P = Fy * Ty;
+    const int p0 = ck * chunk, p1 = min(P, p0 + chunk);
+    float s1[EPT], s2[EPT], mean[EPT], rstd[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        s1[e] = 0.f; s2[e] = 0.f;
+        mean[e] = stats[((int64_t)b * C + cq * EPT + e) * 2];
+        rstd[e] = stats[((int64_t)b * C + cq * EPT + e) * 2 + 1];
+    }
+    if (tid < nact)
+        for (int p = p0 + pl; p < p1; p += ppi) {
+            int f = p / Ty, t = p - f * Ty;
+            if (f >= Fz || t >= Tz) continue;
+            Vec16<T> v = ld16<T>(y + ((int64_t)b * P + p) * C + cq * EPT);
+            Vec16<T> g = ld16<T>(dz + (((int64_t)b * Fz + f) * Tz + t) * C + cq * EPT);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                float yh = (v.get(e) - mean[e]) * rstd[e];
+                float d = g.get(e) * gelu_grad_f(yh);
+                s1[e] += d; s2[e] += d * yh;
+            }
+        }
+    float* dst = partial + (((int64_t)b * gridDim.x + ck) * C) * 2;
+    reduce_channels<EPT>(s1, red, chv, cpp, nact, C);
+    for (int c = tid; c < C; c += NT) dst[c * 2] = chv[c];
+    reduce_channels<EPT>(s2, red, chv, cpp, nact, C);
+    for (int c = tid; c < C; c += NT) dst[c * 2 + 1] = chv[c];
+}
+
+// sums[b][c][2] = sum over chunks / n
+__global__ void in_bwd_finalize(const float* __restrict__ partial, float* __restrict__ sums, int C, int nchunks,
+                                float inv_n) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+        const float* s = partial + (((int64_t)b * nchunks + k) * C + c) * 2;
+        a += s[0]; q += s[1];
+    }
+    sums[((int64_t)b * C + c) * 2] = a * inv_n;
+    sums[((int64_t)b * C + c) * 2 + 1] = q * inv_n;
+}
+
+// dy = rstd * (dyh - m1 - yh*m2) over the full plane
+template <typename T>
+__global__ __launch_bounds__(NT) void in_gelu_bwd_apply(const T* __restrict__ y, const T* __restrict__ dz,
+                                                        const float* __restrict__ stats,
+                                                        const float* __restrict__ sums, T* __restrict__ dy, int B,
+                                                        int Fy, int Ty, int Fz, int Tz, int C) {
+    constexpr int EPT = Vec16<T>::N;
+    const int cpp = C / EPT;
+    const int64_t total = (int64_t)B * Fy * Ty * cpp;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int cq = (int)(i % cpp);
+        int64_t pix = i / cpp;
+        int t = (int)(pix % Ty);
+        int64_t r = pix / Ty;
+        int f = (int)(r % Fy), b = (int)(r / Fy);
+        Vec16<T> v = ld16<T>(y + pix * C + cq * EPT);
+        const bool in = f < Fz && t < Tz;
+        Vec16<T> g = zero16<T>();
+        if (in) g = ld16<T>(dz + (((int64_t)b * Fz + f) * Tz + t) * C + cq * EPT);
+        const float* s = stats + ((int64_t)b * C + cq * EPT) * 2;
+        const float* m = sums + ((int64_t)b * C + cq * EPT) * 2;
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            float yh = (v.get(e) - s[2 * e]) * s[2 * e + 1];
+            float d = in ? g.get(e) * gelu_grad_f(yh) : 0.f;
+            o.set(e, s[2 * e + 1] * (d - m[2 * e] - yh * m[2 * e + 1]));
+        }
+        st16<T>(dy + pix * C + cq * EPT, o);
+    }
+}
+
+// =================== GroupNorm over (gs channels x L rows) ===================
+struct GnGeom {
+    int nslab, NI, L, C, Cp, gs;
+    int64_t OS, IS, RS;            // slab o -> x + (o/NI)*OS + (o%NI)*IS ; row stride RS
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_fwd(const T* __restrict__ x, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, T* __restrict__ xn,
+                                             T* __restrict__ xperm, float* __restrict__ stats, GnGeom g,
+                                             float eps) {
+    constexpr int EPT = Vec16<T>::N;
+    __shared__ float red[NT];
+    __shared__ float gv[128];
+    const int cpp = g.C / EPT, rpi = NT / cpp, nact = rpi * cpp, ng = g.C / g.gs;
+    const int tid = threadIdx.x, rl = tid / cpp, cq = tid % cpp, o = blockIdx.x;
+    const int grp = (cq * EPT) / g.gs;
+    const T* xs = x + (int64_t)(o / g.NI) * g.OS + (int64_t)(o % g.NI) * g.IS + cq * EPT;
+    const float inv = 1.f / (float)(g.gs * g.L);
+    float mean = 0.f, rstd = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        float a = 0.f;
+        if (tid < nact)
+            for (int l = rl; l < g.L; l += rpi) {
+                Vec16<T> v = ld16<T>(xs + (int64_t)l * g.RS);
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) { float d = v.get(e) - mean; a += pass ? d * d : d; }
+            }
+        __syncthreads();
+        red[tid] = (tid < nact) ? a : 0.f;
+        __syncthreads();
+        if (tid < ng) {
+            float s = 0.f;
+            for (int t = 0; t < nact; ++t)
+                if (((t % cpp) * EPT) / g.gs == tid) s += red[t];
+            gv[tid] = s * inv;
+        }
+        __syncthreads();
+        if (pass == 0) mean = gv[grp];
+        else rstd = rsqrtf(gv[grp] + eps);
+    }
+    if (tid < ng && rl == 0) { /* one writer per group: threads tid<ng hold group tid's values in gv */ }
+    if (tid < nact && rl == 0 && (cq * EPT) % g.gs == 0) {
+        stats[((int64_t)o * ng + grp) * 2] = mean;
+        stats[((int64_t)o * ng + grp) * 2 + 1] = rstd;
+    }
+    if (tid < nact) {
+        float ga[EPT], be[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            int cp = (cq * EPT + e) % g.Cp;
+            ga[e] = gamma[cp]; be[e] = beta[cp];
+        }
+        for (int l = rl; l < g.L; l += rpi) {
+            Vec16<T> v = ld16<T>(xs + (int64_t)l * g.RS);
+            Vec16<T> w;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) w.set(e, (v.get(e) - mean) * rstd * ga[e] + be[e]);
+            int64_t oo = ((int64_t)o * g.L + l) * g.C + cq * EPT;
+            st16<T>(xn + oo, w);
+            if (xperm) st16<T>(xperm + oo, v);
+        }
+    }
+}
+
+// backward: dx (strided like x) = gn_bwd(dxn) + dres ; pgb[o][C][2] = {dgamma, dbeta} partials
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd(const T* __restrict__ x, const T* __restrict__ dxn,
+                                             const T* __restrict__ dres, const float* __restrict__ gamma,
+                                             const float* __restrict__ stats, T* __restrict__ dx,
+                                             float* __restrict__ pgb, GnGeom g) {
+    constexpr int EPT = Vec16<T>::N;
+    extern __shared__ float sm[];
+    float* red = sm;                   // NT*EPT
+    float* chv = sm + NT * EPT;        // C
+    __shared__ float r1[NT], r2[NT], g1[128], g2[128];
+    const int cpp = g.C / EPT, rpi = NT / cpp, nact = rpi * cpp, ng = g.C / g.gs;
+    const int tid = threadIdx.x, rl = tid / cpp, cq = tid % cpp, o = blockIdx.x;
+    const int grp = (cq * EPT) / g.gs;
+    const int64_t xoff = (int64_t)(o / g.NI) * g.OS + (int64_t)(o % g.NI) * g.IS + cq * EPT;
+    float mean = 0.f, rstd = 0.f;
+    if (tid < nact) { mean = stats[((int64_t)o * ng + grp) * 2]; rstd = stats[((int64_t)o * ng + grp) * 2 + 1]; }
+    float ga[EPT], dg[EPT], db[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { ga[e] = (tid < nact) ? gamma[(cq * EPT + e) % g.Cp] : 0.f; dg[e] = 0.f; db[e] = 0.f; }
+    float a1 = 0.f, a2 = 0.f;
+    if (tid < nact)
+        for (int l = rl; l < g.L; l += rpi) {
+            Vec16<T> v = ld16<T>(x + xoff + (int64_t)l * g.RS);
+            Vec16<T> d = ld16<T>(dxn + ((int64_t)o * g.L + l) * g.C + cq * EPT);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                float xh = (v.get(e) - mean) * rstd, dd = d.get(e), gg = dd * ga[e];
+                a1 += gg; a2 += gg * xh;
+                dg[e] += dd * xh; db[e] += dd;
+            }
+        }
+    r1[tid] = (tid < nact) ? a1 : 0.f;
+    r2[tid] = (tid < nact) ? a2 : 0.f;
+    __syncthreads();
+    if (tid < ng) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int t = 0; t < nact; ++t)
+            if (((t % cpp) * EPT) / g.gs == tid) { s1 += r1[t]; s2 += r2[t]; }
+        const float inv = 1.f / (float)(g.gs * g.L);
+        g1[tid] = s1 * inv; g2[tid] = s2 * inv;
+    }
+    __syncthreads();
+    const float m1 = g1[grp], m2 = g2[grp];
+    if (tid < nact)
+        for (int l = rl; l < g.L; l += rpi) {
+            Vec16<T> v = ld16<T>(x + xoff + (int64_t)l * g.RS);
+            int64_t oo = ((int64_t)o * g.L + l) * g.C + cq * EPT;
+            Vec16<T> d = ld16<T>(dxn + oo);
+            Vec16<T> w;
+            if (dres) {
+                Vec16<T> r = ld16<T>(dres + oo);
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    float xh = (v.get(e) - mean) * rstd;
+                    w.set(e, rstd * (d.get(e) * ga[e] - m1 - xh * m2) + r.get(e));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    float xh = (v.get(e) - mean) * rstd;
+                    w.set(e, rstd * (d.get(e) * ga[e] - m1 - xh * m2));
+                }
+            }
+            st16<T>(dx + xoff + (int64_t)l * g.RS, w);
+        }
+    reduce_channels<EPT>(dg, red, chv, cpp, nact, g.C);
+    for (int c = tid; c < g.C; c += NT) pgb[((int64_t)o * g.C + c) * 2] = chv[c];
+    reduce_channels<EPT>(db, red, chv, cpp, nact, g.C);
+    for (int c = tid; c < g.C; c += NT) pgb[((int64_t)o * g.C + c) * 2 + 1] = chv[c];
+}
+
+// =================== column sums: out[chunk][w] = sum_{r in chunk} in[r][w] ===================
+template <typename T>
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t R,
+                                                    int W, int64_t ld, int64_t rows_per) {
+    int w = blockIdx.x * NT + threadIdx.x;
+    if (w >= W) return;
+    int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += ldf(in + r * ld + w);
+    out[(int64_t)blockIdx.y * W + w] = s;
+}
+
+int ept_of(int dtype) { return dtype ? 8 : 4; }
+
+}  // namespace
+
+#define ST reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int dtt_in_stats(const void* y, float* partial, float* stats, int B, int P, int C, int chunk, float eps,
+                            int dtype, void* stream) {
+    const int ept = ept_of(dtype);
+    DTT_CHECK(C % ept == 0 && C / ept <= NT && C <= 2048, "dtt_in_stats: unsupported C=%d", C);
+    DTT_CHECK(chunk > 0 && B > 0 && P > 0, "dtt_in_stats: bad shape");
+    const int nch = (P + chunk - 1) / chunk;
+    size_t sm = (NT * ept + C) * sizeof(float);
+    if (dtype) hipLaunchKernelGGL(in_stats_partial<bf16>, dim3(nch, B), dim3(NT), sm, ST, (const bf16*)y, partial, P, C, chunk);
+    else hipLaunchKernelGGL(in_stats_partial<float>, dim3(nch, B), dim3(NT), sm, ST, (const float*)y, partial, P, C, chunk);
+    hipLaunchKernelGGL(in_stats_finalize, dim3((C + 127) / 128, B), dim3(128), 0, ST, partial, stats, P, C, chunk, nch, eps);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_in_gelu_fwd(const void* y, const float* stats, void* z, int B, int Fy, int Ty, int Fz, int Tz,
+                               int C, int dtype, void* stream) {
+    const int ept = ept_of(dtype);
+    DTT_CHECK(C % ept == 0 && Fz <= Fy && Tz <= Ty, "dtt_in_gelu_fwd: bad shape");
+    int64_t total = (int64_t)B * Fz * Tz * (C / ept);
+    int grid = (int)min<int64_t>((total + NT - 1) / NT, 8192);
+    if (dtype) hipLaunchKernelGGL(in_gelu_fwd<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)y, stats, (bf16*)z, B, Fy, Ty, Fz, Tz, C);
+    else hipLaunchKernelGGL(in_gelu_fwd<float>, dim3(grid), dim3(NT), 0, ST, (const float*)y, stats, (float*)z, B, Fy, Ty, Fz, Tz, C);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_in_gelu_bwd(const void* y, const void* dz, const float* stats, float* partial, float* sums,
+                               void* dy, int B, int Fy, int Ty, int Fz, int Tz, int C, int chunk, int dtype,
+                               void* stream) {
+    const int ept = ept_of(dtype);
+    DTT_CHECK(C % ept == 0 && C / ept <= NT && C <= 2048 && Fz <= Fy && Tz <= Ty && chunk > 0,
+              "dtt_in_gelu_bwd: bad shape");
+    const int P = Fy * Ty, nch = (P + chunk - 1) / chunk;
+    size_t sm = (NT * ept + C) * sizeof(float);
+    if (dtype) hipLaunchKernelGGL(in_gelu_bwd_partial<bf16>, dim3(nch, B), dim3(NT), sm, ST, (const bf16*)y, (const bf16*)dz, stats, partial, Fy, Ty, Fz, Tz, C, chunk);
+    else hipLaunchKernelGGL(in_gelu_bwd_partial<float>, dim3(nch, B), dim3(NT), sm, ST, (const float*)y, (const float*)dz, stats, partial, Fy, Ty, Fz, Tz, C, chunk);
+    hipLaunchKernelGGL(in_bwd_finalize, dim3((C + 127) / 128, B), dim3(128), 0, ST, partial, sums, C, nch, 1.f / (float)P);
+    int64_t total = (int64_t)B * P * (C / ept);
+    int grid = (int)min<int64_t>((total + NT - 1) / NT, 8192);
+    if (dtype) hipLaunchKernelGGL(in_gelu_bwd_apply<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)y, (const bf16*)dz, stats, sums, (bf16*)dy, B, Fy, Ty, Fz, Tz, C);
+    else hipLaunchKernelGGL(in_gelu_bwd_apply<float>, dim3(grid), dim3(NT), 0, ST, (const float*)y, (const float*)dz, stats, sums, (float*)dy, B, Fy, Ty, Fz, Tz, C);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+static int gn_check(const GnGeom& g, int ept) {
+    DTT_CHECK(g.C % ept == 0 && g.C / ept <= NT && g.gs % ept == 0 && g.C % g.gs == 0 && g.C / g.gs <= 128 &&
+                  g.Cp % g.gs == 0 && g.C % g.Cp == 0 && g.nslab > 0 && g.L > 0 && g.NI > 0 && g.C <= 2048,
+              "groupnorm: unsupported geometry C=%d Cp=%d gs=%d", g.C, g.Cp, g.gs);
+    return 0;
+}
+
+extern "C" int dtt_gn_fwd(const void* x, const float* gamma, const float* beta, void* xn, void* xperm, float* stats,
+                          int nslab, int NI, int L, int C, int Cp, int gs, int64_t OS, int64_t IS, int64_t RS,
+                          float eps, int dtype, void* stream) {
+    GnGeom g{nslab, NI, L, C, Cp, gs, OS, IS, RS};
+    if (gn_check(g, ept_of(dtype))) return -1;
+    if (dtype) hipLaunchKernelGGL(gn_fwd<bf16>, dim3(nslab), dim3(NT), 0, ST, (const bf16*)x, gamma, beta, (bf16*)xn, (bf16*)xperm, stats, g, eps);
+    else hipLaunchKernelGGL(gn_fwd<float>, dim3(nslab), dim3(NT), 0, ST, (const float*)x, gamma, beta, (float*)xn, (float*)xperm, stats, g, eps);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_gn_bwd(const void* x, const void* dxn, const void* dres, const float* gamma, const float* stats,
+                          void* dx, float* pgb, int nslab, int NI, int L, int C, int Cp, int gs, int64_t OS,
+                          int64_t IS, int64_t RS, int dtype, void* stream) {
+    GnGeom g{nslab, NI, L, C, Cp, gs, OS, IS, RS};
+    const int ept = ept_of(dtype);
+    if (gn_check(g, ept)) return -1;
+    size_t sm = (NT * ept + C) * sizeof(float);
+    if (dtype) hipLaunchKernelGGL(gn_bwd<bf16>, dim3(nslab), dim3(NT), sm, ST, (const bf16*)x, (const bf16*)dxn, (const bf16*)dres, gamma, stats, (bf16*)dx, pgb, g);
+    else hipLaunchKernelGGL(gn_bwd<float>, dim3(nslab), dim3(NT), sm, ST, (const float*)x, (const float*)dxn, (const float*)dres, gamma, stats, (float*)dx, pgb, g);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[nchunks][W]; call again on `out` with nchunks=1 to finish (deterministic two-stage sum)
+extern "C" int dtt_colsum(const void* in, float* out, int64_t R, int W, int64_t ld, int nchunks, int dtype,
+                          void* stream) {
+    DTT_CHECK(R > 0 && W > 0 && nchunks > 0 && nchunks <= 65535, "dtt_colsum: bad shape");
+    int64_t per = (R + nchunks - 1) / nchunks;
+    dim3 grid((W + NT - 1) / NT, nchunks);
+    if (dtype) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(NT), 0, ST, (const bf16*)in, out, R, W, ld, per);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(NT), 0, ST, (const float*)in, out, R, W, ld, per);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}

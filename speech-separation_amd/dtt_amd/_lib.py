@@ -1,0 +1,92 @@
+"""ctypes binding of libdtt_hip.so (include/dtt_hip.h).
+
+There is no CPU fallback: if the library is missing, or a tensor is not on a
+GPU, every op raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdtt_hip.so")
+_lib = None
+
+
+class DttError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise DttError(
+                f"{_LIB_PATH} not found: build it with `make -C speech-separation_amd/csrc` "
+                "(or __graft_entry__.build()). There is no fallback path.")
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.dtt_last_error.restype = C.c_char_p
+        _lib.dtt_version.restype = C.c_int
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DttError(f"{what} failed ({rc}): {lib().dtt_last_error().decode()}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DttError("dtt_amd ops need CUDA(HIP) tensors; there is no CPU path")
+    return C.c_void_p(t.data_ptr())
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return 0
+    if dt == torch.bfloat16:
+        return 1
+    raise DttError(f"unsupported dtype {dt}")
+
+
+class DttGemm(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
+        ("a_ms", C.c_int64), ("a_ks", C.c_int64), ("a_bs", C.c_int64),
+        ("b_ks", C.c_int64), ("b_ns", C.c_int64), ("b_bs", C.c_int64),
+        ("c_ms", C.c_int64), ("c_ns", C.c_int64), ("c_bs", C.c_int64),
+        ("r_ms", C.c_int64), ("r_ns", C.c_int64), ("r_bs", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32), ("splitk", C.c_int32),
+        ("dtype", C.c_int32), ("out_f32", C.c_int32), ("atomic", C.c_int32), ("bias_mode", C.c_int32),
+        ("act", C.c_int32), ("alpha", C.c_float),
+        ("a_mode", C.c_int32), ("b_mode", C.c_int32),
+        ("cB", C.c_int32), ("cFi", C.c_int32), ("cTi", C.c_int32), ("cCi", C.c_int32),
+        ("cFo", C.c_int32), ("cTo", C.c_int32), ("cstride", C.c_int32), ("ctrans", C.c_int32),
+        ("sh_shift", C.c_int32), ("sh_heads", C.c_int32), ("sh_L", C.c_int32), ("sh_edge", C.c_int32),
+    ]
+
+
+def gemm_raw(**kw):
+    """Launch dtt_gemm from keyword fields (tensors for A/B/C/bias/R)."""
+    g = DttGemm()
+    keep = []
+    for k in ("A", "B", "C", "bias", "R"):
+        t = kw.pop(k, None)
+        if t is not None:
+            if not t.is_cuda:
+                raise DttError("dtt_amd ops need CUDA(HIP) tensors; there is no CPU path")
+            keep.append(t)
+            setattr(g, k, t.data_ptr())
+    kw.setdefault("batch", 1)
+    kw.setdefault("splitk", 1)
+    kw.setdefault("alpha", 1.0)
+    for k, v in kw.items():
+        setattr(g, k, v)
+    check(lib().dtt_gemm(C.byref(g), stream_ptr()), "dtt_gemm")

@@ -1,0 +1,162 @@
+"""GPU: dtt_gemm (MFMA GEMM + gather loaders) against fp64 CPU math.
+fp32 mode uses the exact-f32 MFMA: tolerance 1e-5 relative; bf16: 1e-2."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from helpers import rel_err  # noqa: E402
+
+TOL = {torch.float32: 1e-5, torch.bfloat16: 1e-2}
+
+
+def _mk(shape, dt, g):
+    return torch.randn(shape, generator=g).to(dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (513, 70, 257), (33, 300, 520), (200, 31, 40),
+                                   (64, 64, 1032), (1, 1, 8)])
+def test_gemm_nt_nn_tn(dt, M, N, K):
+    from dtt_amd._lib import gemm_raw, dtype_code
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    dev = "cuda"
+    a = _mk((M, K), dt, g)
+    b = _mk((K, N), dt, g)
+    bias_n = torch.randn(N, generator=g)
+    bias_m = torch.randn(M, generator=g)
+    r = _mk((M, N), dt, g)
+    ref = a.double() @ b.double()
+    ad, bd, rd = a.to(dev), b.to(dev), r.to(dev)
+    # NT: A[m,k] k-contig, B stored [n,k] k-contig
+    bt = b.t().contiguous().to(dev)
+    c = torch.empty(M, N, dtype=dt, device=dev)
+    gemm_raw(A=ad, B=bt, C=c, bias=bias_n.to(dev), R=rd, M=M, N=N, K=K, a_ms=K, a_ks=1, b_ks=1, b_ns=K,
+             c_ms=N, c_ns=1, r_ms=N, r_ns=1, dtype=dtype_code(dt), bias_mode=1)
+    assert rel_err(c, ref + bias_n.double() + r.double()) < TOL[dt]
+    # NN: B[k,n] n-contig, per-m bias, fp32 output
+    c = torch.empty(M, N, dtype=torch.float32, device=dev)
+    gemm_raw(A=ad, B=bd, C=c, bias=bias_m.to(dev), M=M, N=N, K=K, a_ms=K, a_ks=1, b_ks=N, b_ns=1,
+             c_ms=N, c_ns=1, dtype=dtype_code(dt), bias_mode=2, out_f32=1)
+    assert rel_err(c, ref + bias_m.double()[:, None]) < TOL[dt]
+    # TN: A stored [k,m] m-contig, transposed output (c_ms = 1), GELU
+    at = a.t().contiguous().to(dev)
+    c = torch.empty(N, M, dtype=dt, device=dev)
+    gemm_raw(A=at, B=bd, C=c, M=M, N=N, K=K, a_ms=1, a_ks=M, b_ks=N, b_ns=1, c_ms=1, c_ns=M,
+             dtype=dtype_code(dt), act=1, alpha=0.5)
+    assert rel_err(c.t(), F.gelu(0.5 * ref)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_batched_splitk_atomic(dt):
+    from dtt_amd._lib import gemm_raw, dtype_code
+    g = torch.Generator().manual_seed(5)
+    dev = "cuda"
+    Bn, M, N, K = 3, 24, 40, 1000
+    a = _mk((Bn, K, M), dt, g)           # [k, m] per batch: TN wgrad form
+    b = _mk((Bn, K, N), dt, g)
+    ref = torch.einsum("bkm,bkn->mn", a.double(), b.double())       # reduce over batch too
+    c = torch.zeros(M, N, dtype=torch.float32, device=dev)
+    gemm_raw(A=a.to(dev), B=b.to(dev), C=c, M=M, N=N, K=K, batch=Bn, splitk=4, a_ms=1, a_ks=M, a_bs=K * M,
+             b_ks=N, b_ns=1, b_bs=K * N, c_ms=N, c_ns=1, c_bs=0, dtype=dtype_code(dt), atomic=1, out_f32=1)
+    assert rel_err(c, ref) < TOL[dt]
+    # batched, distinct outputs
+    c = torch.empty(Bn, M, N, dtype=dt, device=dev)
+    gemm_raw(A=a.to(dev), B=b.to(dev), C=c, M=M, N=N, K=K, batch=Bn, a_ms=1, a_ks=M, a_bs=K * M,
+             b_ks=N, b_ns=1, b_bs=K * N, c_ms=N, c_ns=1, c_bs=M * N, dtype=dtype_code(dt))
+    assert rel_err(c, torch.einsum("bkm,bkn->bmn", a.double(), b.double())) < TOL[dt]
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Ci,Co,Fi,Ti,stride", [(8, 16, 9, 7, 1), (32, 32, 33, 20, 1), (16, 32, 17, 13, 2),
+                                                (64, 128, 10, 6, 2)])
+def test_conv_implicit_gemm_fwd_and_wgrad(dt, Ci, Co, Fi, Ti, stride):
+    from dtt_amd._lib import gemm_raw, dtype_code
+    g = torch.Generator().manual_seed(Ci + Co + Fi)
+    dev = "cuda"
+    Bn = 2
+    x = _mk((Bn, Ci, Fi, Ti), dt, g)
+    w = (_mk((Co, Ci, 3, 3), dt, g).float() / (3 * Ci ** 0.5)).to(dt)
+    bias = torch.randn(Co, generator=g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride=stride, padding=1)
+    Fo, To = ref.shape[2], ref.shape[3]
+    wp = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()     # [co][tap][ci]
+    xd = _nhwc(x).to(dev)
+    y = torch.empty(Bn, Fo, To, Co, dtype=dt, device=dev)
+    geom = dict(cB=Bn, cFi=Fi, cTi=Ti, cCi=Ci, cFo=Fo, cTo=To, cstride=stride, ctrans=0)
+    gemm_raw(A=xd, B=wp.to(dev), C=y, bias=bias.to(dev), M=Bn * Fo * To, N=Co, K=9 * Ci, a_ms=0, a_ks=1,
+             b_ks=1, b_ns=9 * Ci, c_ms=Co, c_ns=1, dtype=dtype_code(dt), bias_mode=1, a_mode=1, **geom)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL[dt]
+    # wgrad: dW[co][tap][ci] = sum_p dy[p,co] * x[src(p,tap),ci]
+    dy = _mk((Bn, Co, Fo, To), dt, g)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=stride, padding=1).backward(dy.double())
+    dwp = torch.zeros(Co, 9, Ci, dtype=torch.float32, device=dev)
+    P = Bn * Fo * To
+    gemm_raw(A=_nhwc(dy).to(dev), B=xd, C=dwp, M=Co, N=Ci, K=P, batch=9, splitk=3, a_ms=1, a_ks=Co, a_bs=0,
+             b_ks=Ci, b_ns=1, b_bs=0, c_ms=9 * Ci, c_ns=1, c_bs=Ci, dtype=dtype_code(dt), atomic=1,
+             out_f32=1, b_mode=1, **geom)
+    ref_dw = wr.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)
+    assert rel_err(dwp, ref_dw) < TOL[dt]
+    # dgrad through the same kernel: stride 1 -> flipped-weight conv; stride 2 -> transposed gather
+    if stride == 1:
+        wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, 9 * Co).contiguous()     # [ci][tap'][co]
+        gd = dict(cB=Bn, cFi=Fo, cTi=To, cCi=Co, cFo=Fi, cTo=Ti, cstride=1, ctrans=0)
+    else:
+        wd = w.permute(1, 2, 3, 0).reshape(Ci, 9 * Co).contiguous()
+        gd = dict(cB=Bn, cFi=Fo, cTi=To, cCi=Co, cFo=Fi, cTo=Ti, cstride=2, ctrans=1)
+    dx = torch.empty(Bn, Fi, Ti, Ci, dtype=dt, device=dev)
+    gemm_raw(A=_nhwc(dy).to(dev), B=wd.to(dev), C=dx, M=Bn * Fi * Ti, N=Ci, K=9 * Co, a_ms=0, a_ks=1, b_ks=1,
+             b_ns=9 * Co, c_ms=Ci, c_ns=1, dtype=dtype_code(dt), a_mode=1, **gd)
+    assert rel_err(dx.permute(0, 3, 1, 2), xr.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_conv_transposed_cropped(dt):
+    """ConvTranspose2d(3, stride 2, pad 1, output_padding 1) + crop (decoder.py:46-52)."""
+    from dtt_amd._lib import gemm_raw, dtype_code
+    g = torch.Generator().manual_seed(9)
+    dev = "cuda"
+    Bn, Ci, Co, Fi, Ti = 2, 32, 16, 9, 7
+    Fs, Ts = 17, 13                                            # skip size (crop of 18 x 14)
+    x = _mk((Bn, Ci, Fi, Ti), dt, g)
+    w = (_mk((Ci, Co, 3, 3), dt, g).float() / (3 * Ci ** 0.5)).to(dt)
+    ref = F.conv_transpose2d(x.double(), w.double(), None, stride=2, padding=1, output_padding=1)[:, :, :Fs, :Ts]
+    wp = w.permute(1, 2, 3, 0).reshape(Co, 9 * Ci).contiguous()     # [co][tap][ci]
+    y = torch.empty(Bn, Fs, Ts, Co, dtype=dt, device=dev)
+    gemm_raw(A=_nhwc(x).to(dev), B=wp.to(dev), C=y, M=Bn * Fs * Ts, N=Co, K=9 * Ci, a_ms=0, a_ks=1, b_ks=1,
+             b_ns=9 * Ci, c_ms=Co, c_ns=1, dtype=dtype_code(dt), a_mode=1, cB=Bn, cFi=Fi, cTi=Ti, cCi=Ci,
+             cFo=Fs, cTo=Ts, cstride=2, ctrans=1)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_row_shift(dt):
+    """dW_hh form: C[m][n] = sum_r dG[r][m] * y[r + shift][n], zero at sequence edges."""
+    from dtt_amd._lib import gemm_raw, dtype_code
+    g = torch.Generator().manual_seed(3)
+    dev = "cuda"
+    outer, L, heads, G, H = 3, 5, 2, 48, 24
+    R = outer * L * heads
+    dG = _mk((R, G), dt, g)
+    y = _mk((R, 2 * H), dt, g)
+    for shift_steps, edge, col0 in ((-1, 0, 0), (1, L - 1, H)):
+        yy = y.double().view(outer, L, heads, 2 * H)[..., col0:col0 + H]
+        prev = torch.zeros_like(yy)
+        if shift_steps < 0:
+            prev[:, 1:] = yy[:, :-1]
+        else:
+            prev[:, :-1] = yy[:, 1:]
+        ref = dG.double().t() @ prev.reshape(R, H)
+        c = torch.zeros(G, H, dtype=torch.float32, device=dev)
+        yd = y.to(dev)
+        gemm_raw(A=dG.to(dev), B=yd[:, col0:], C=c, M=G, N=H, K=R, splitk=2, a_ms=1, a_ks=G, b_ks=2 * H, b_ns=1,
+                 c_ms=H, c_ns=1, dtype=dtype_code(dt), atomic=1, out_f32=1, b_mode=2,
+                 sh_shift=shift_steps * heads, sh_heads=heads, sh_L=L, sh_edge=edge)
+        assert rel_err(c, ref) < TOL[dt]

@@ -78,3 +78,27 @@ def synth_video(B: int, T_v: int, seed: int = 0, H: int = 88, W: int = 88):
     g = _gen("synth_video", seed)
     v = torch.rand(B, 2, T_v, H, W, generator=g)
     return (v - 0.421) / 0.165
+
+
+def stable_stft(x, n_fft, hop):
+    """Machine-portable STFT features for fixtures: float64 DFT, then imaginary
+    parts that are pure rounding noise (|im| < 1e-9 |re|, e.g. the reflect-padded
+    first frame, which is symmetric) are snapped to +0 so that ``angle`` does not
+    flip between -pi and +pi from one CPU's FFT rounding to another's.  Returns
+    fp32 (mag, phase) [B, F, T]; same recipe as oracle.stft_mag_phase otherwise."""
+    import math
+    import torch.nn.functional as F
+    xd = x.double()
+    pad = n_fft // 2
+    xp = F.pad(xd.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    frames = xp.unfold(-1, n_fft, hop)
+    n = torch.arange(n_fft, dtype=torch.float64)
+    win = 0.5 - 0.5 * torch.cos(2.0 * math.pi * n / n_fft)
+    spec = torch.fft.rfft(frames * win, dim=-1).transpose(1, 2)
+    re, im = spec.real.clone(), spec.imag.clone()
+    scale = frames.abs().amax(dim=-1).unsqueeze(1) * n_fft          # [B,1,T] magnitude scale of a frame
+    im = torch.where(im.abs() < 1e-9 * (re.abs() + 1e-3 * scale), torch.zeros_like(im), im)
+    re = torch.where(re.abs() < 1e-12 * scale, torch.zeros_like(re), re)
+    mag = torch.sqrt(re * re + im * im).float()
+    phase = torch.atan2(im, re).float()
+    return mag, phase

@@ -70,6 +70,43 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+
+// ---- MFMA 32x32 tile helpers: one 16-wide K chunk per call.  Lane l holds row/col
+// (l & 31) and the 8 k values 8*(l>>5)..+7 of the chunk (bf16: one x16 MFMA; f32:
+// eight 32x32x2 MFMAs, instruction j contracting k in {j, 8+j}).
+template <typename T> struct MM;
+template <> struct MM<bf16> {
+    static constexpr int EPT = 8;
+    static constexpr int PAD = 8;            // LDS row pad (elements): 80-byte rows at BK=32
+    typedef s16x8_t Frag;
+    static __device__ __forceinline__ Frag ldfrag(const bf16* p) { return *reinterpret_cast<const s16x8_t*>(p); }
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                      acc, 0, 0, 0);
+    }
+};
+template <> struct MM<float> {
+    static constexpr int EPT = 4;
+    static constexpr int PAD = 4;            // 144-byte rows at BK=32
+    struct Frag { float4 lo, hi; };
+    static __device__ __forceinline__ Frag ldfrag(const float* p) {
+        Frag f;
+        f.lo = *reinterpret_cast<const float4*>(p);
+        f.hi = *reinterpret_cast<const float4*>(p + 4);
+        return f;
+    }
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.x, b.lo.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.y, b.lo.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.z, b.lo.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.w, b.lo.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.x, b.hi.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.y, b.hi.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.z, b.hi.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.w, b.hi.w, acc, 0, 0, 0);
+    }
+};
+
 // Host side error plumbing (api.cpp)
 extern "C" const char* dtt_last_error();
 void dtt_set_error(const char* fmt, ...);

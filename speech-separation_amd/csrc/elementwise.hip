@@ -1,0 +1,229 @@
+// Small HBM-bound elementwise kernels on channels-last tensors: residual add,
+// multiplicative U-Net skip (decoder.py:43), FiLM apply (block_fusion.py:30-37),
+// frequency-mean tokens and broadcast-concat of the cross-attention fusion
+// (cross_attention_positional.py:55,77-78).
+#include "common.h"
+#include "../../include/dtt_hip.h"
+
+namespace {
+constexpr int NT = 256;
+
+template <typename T, int OP>
+__global__ __launch_bounds__(NT) void binary_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                    T* __restrict__ out, int64_t nvec) {
+    constexpr int EPT = Vec16<T>::N;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * NT) {
+        Vec16<T> x = ld16<T>(a + i * EPT), y = ld16<T>(b + i * EPT), o;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) o.set(e, OP == 0 ? x.get(e) + y.get(e) : x.get(e) * y.get(e));
+        st16<T>(out + i * EPT, o);
+    }
+}
+
+// FiLM: y[b,f,t,c] = (1 + gc[b,t,c] + gf[b,t,f]) * x + bc[b,t,c] + bf[b,t,f]
+// gb_c: [B][T][2C] = (gamma_c | beta_c), gb_f: [B][T][2F] = (gamma_f | beta_f), both f32
+template <typename T>
+__global__ __launch_bounds__(NT) void film_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gbc,
+                                                      const float* __restrict__ gbf, T* __restrict__ y, int B, int F,
+                                                      int Tn, int C) {
+    constexpr int EPT = Vec16<T>::N;
+    const int cpp = C / EPT;
+    const int64_t total = (int64_t)B * F * Tn * cpp;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int cq = (int)(i % cpp);
+        int64_t pix = i / cpp;
+        int t = (int)(pix % Tn);
+        int64_t r = pix / Tn;
+        int f = (int)(r % F), b = (int)(r / F);
+        const float* pc = gbc + ((int64_t)b * Tn + t) * 2 * C + cq * EPT;
+        const float* pf = gbf + ((int64_t)b * Tn + t) * 2 * F;
+        float gf = pf[f], bf = pf[F + f];
+        Vec16<T> v = ld16<T>(x + pix * C + cq * EPT), o;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) o.set(e, (1.f + pc[e] + gf) * v.get(e) + pc[C + e] + bf);
+        st16<T>(y + pix * C + cq * EPT, o);
+    }
+}
+
+// FiLM backward: dx = (1+gamma) * dy ; per (b,t): dgc[c] = sum_f dy*x, dbc[c] = sum_f dy,
+// dgf[f] = sum_c dy*x, dbf[f] = sum_c dy.  One block per (b,t).
+template <typename T>
+__global__ __launch_bounds__(NT) void film_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                      const float* __restrict__ gbc, const float* __restrict__ gbf,
+                                                      T* __restrict__ dx, float* __restrict__ dgbc,
+                                                      float* __restrict__ dgbf, int B, int F, int Tn, int C) {
+    constexpr int EPT = Vec16<T>::N;
+    extern __shared__ float sm[];          // 2*NT*EPT
+    const int cpp = C / EPT, fpi = NT / cpp, nact = fpi * cpp;
+    const int tid = threadIdx.x, fl = tid / cpp, cq = tid % cpp;
+    const int b = blockIdx.x / Tn, t = blockIdx.x % Tn;
+    const float* pc = gbc + ((int64_t)b * Tn + t) * 2 * C + cq * EPT;
+    const float* pf = gbf + ((int64_t)b * Tn + t) * 2 * F;
+    float* dpf = dgbf + ((int64_t)b * Tn + t) * 2 * F;
+    float ag[EPT], ab[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { ag[e] = 0.f; ab[e] = 0.f; }
+    for (int f0 = 0; f0 < F; f0 += fpi) {
+        const int f = f0 + fl;
+        float sg = 0.f, sb = 0.f;
+        if (tid < nact && f < F) {
+            int64_t o = (((int64_t)b * F + f) * Tn + t) * C + cq * EPT;
+            Vec16<T> v = ld16<T>(x + o), g = ld16<T>(dy + o), w;
+            float gf = pf[f];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                float gg = g.get(e), xv = v.get(e);
+                w.set(e, (1.f + pc[e] + gf) * gg);
+                ag[e] += gg * xv; ab[e] += gg;
+                sg += gg * xv; sb += gg;
+            }
+            st16<T>(dx + o, w);
+        }
+        // reduce sg/sb over the cpp threads of one f (consecutive tids)
+        __syncthreads();
+        sm[tid] = sg; sm[NT + tid] = sb;
+        __syncthreads();
+        if (tid < fpi && f0 + tid < F) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int k = 0; k < cpp; ++k) { s1 += sm[tid * cpp + k]; s2 += sm[NT + tid * cpp + k]; }
+            dpf[f0 + tid] = s1; dpf[F + f0 + tid] = s2;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { sm[tid * EPT + e] = (tid < nact) ? ag[e] : 0.f; sm[NT * EPT + tid * EPT + e] = (tid < nact) ? ab[e] : 0.f; }
+    __syncthreads();
+    float* dpc = dgbc + ((int64_t)b * Tn + t) * 2 * C;
+    for (int c = tid; c < C; c += NT) {
+        int q = c / EPT, e = c % EPT;
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = q; k < nact; k += cpp) { s1 += sm[k * EPT + e]; s2 += sm[NT * EPT + k * EPT + e]; }
+        dpc[c] = s1; dpc[C + c] = s2;
+    }
+}
+
+// tokens[b][t][c] = mean_f x[b,f,t,c]   (f32 out)
+template <typename T>
+__global__ __launch_bounds__(NT) void fmean_kernel(const T* __restrict__ x, float* __restrict__ tok, int B, int F,
+                                                   int Tn, int C) {
+    const int64_t total = (int64_t)B * Tn * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int c = (int)(i % C);
+        int64_t r = i / C;
+        int t = (int)(r % Tn), b = (int)(r / Tn);
+        float s = 0.f;
+        for (int f = 0; f < F; ++f) s += ldf(x + (((int64_t)b * F + f) * Tn + t) * C + c);
+        tok[i] = s / (float)F;
+    }
+}
+
+// out[b,f,t,0:C] = x ; out[b,f,t,C:2C] = enh[b,t,c] (f32 tokens)
+template <typename T>
+__global__ __launch_bounds__(NT) void bcat_fwd_kernel(const T* __restrict__ x, const float* __restrict__ enh,
+                                                      T* __restrict__ out, int B, int F, int Tn, int C) {
+    constexpr int EPT = Vec16<T>::N;
+    const int cpp = 2 * C / EPT, half = C / EPT;
+    const int64_t total = (int64_t)B * F * Tn * cpp;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int cq = (int)(i % cpp);
+        int64_t pix = i / cpp;
+        Vec16<T> v;
+        if (cq < half) v = ld16<T>(x + pix * C + cq * EPT);
+        else {
+            int t = (int)(pix % Tn);
+            int b = (int)(pix / ((int64_t)F * Tn));
+            const float* e0 = enh + ((int64_t)b * Tn + t) * C + (cq - half) * EPT;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) v.set(e, e0[e]);
+        }
+        st16<T>(out + pix * 2 * C + cq * EPT, v);
+    }
+}
+
+// dx[b,f,t,c] = dout[...,c] + dtok[b,t,c]/F ; denh[b,t,c] = sum_f dout[...,C+c]
+template <typename T>
+__global__ __launch_bounds__(NT) void bcat_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ dtok,
+                                                      T* __restrict__ dx, float* __restrict__ denh, int B, int F,
+                                                      int Tn, int C) {
+    const int64_t total = (int64_t)B * Tn * C;
+    const float invF = 1.f / (float)F;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        int c = (int)(i % C);
+        int64_t r = i / C;
+        int t = (int)(r % Tn), b = (int)(r / Tn);
+        float s = 0.f, dt = dtok ? dtok[i] * invF : 0.f;
+        for (int f = 0; f < F; ++f) {
+            int64_t pix = ((int64_t)b * F + f) * Tn + t;
+            s += ldf(dout + pix * 2 * C + C + c);
+            stf(dx + pix * C + c, ldf(dout + pix * 2 * C + c) + dt);
+        }
+        if (denh) denh[i] = s;
+    }
+}
+
+int ept_of(int dtype) { return dtype ? 8 : 4; }
+int grid_for(int64_t total) { int64_t g = (total + NT - 1) / NT; return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192); }
+}  // namespace
+
+#define ST reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int dtt_binary(int op, const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+    const int ept = ept_of(dtype);
+    DTT_CHECK(n > 0 && n % ept == 0 && (op == 0 || op == 1), "dtt_binary: n=%lld must be a multiple of %d", (long long)n, ept);
+    int64_t nv = n / ept;
+    int grid = grid_for(nv);
+#define BK(TT, OP) hipLaunchKernelGGL((binary_kernel<TT, OP>), dim3(grid), dim3(NT), 0, ST, (const TT*)a, (const TT*)b, (TT*)out, nv)
+    if (dtype) { if (op) BK(bf16, 1); else BK(bf16, 0); }
+    else { if (op) BK(float, 1); else BK(float, 0); }
+#undef BK
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_film_fwd(const void* x, const float* gbc, const float* gbf, void* y, int B, int F, int T, int C,
+                            int dtype, void* stream) {
+    DTT_CHECK(C % ept_of(dtype) == 0, "dtt_film_fwd: C=%d", C);
+    int grid = grid_for((int64_t)B * F * T * (C / ept_of(dtype)));
+    if (dtype) hipLaunchKernelGGL(film_fwd_kernel<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)x, gbc, gbf, (bf16*)y, B, F, T, C);
+    else hipLaunchKernelGGL(film_fwd_kernel<float>, dim3(grid), dim3(NT), 0, ST, (const float*)x, gbc, gbf, (float*)y, B, F, T, C);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_film_bwd(const void* x, const void* dy, const float* gbc, const float* gbf, void* dx, float* dgbc,
+                            float* dgbf, int B, int F, int T, int C, int dtype, void* stream) {
+    const int ept = ept_of(dtype);
+    DTT_CHECK(C % ept == 0 && C / ept <= NT, "dtt_film_bwd: C=%d", C);
+    size_t sm = (size_t)2 * NT * ept * sizeof(float);
+    if (dtype) hipLaunchKernelGGL(film_bwd_kernel<bf16>, dim3(B * T), dim3(NT), sm, ST, (const bf16*)x, (const bf16*)dy, gbc, gbf, (bf16*)dx, dgbc, dgbf, B, F, T, C);
+    else hipLaunchKernelGGL(film_bwd_kernel<float>, dim3(B * T), dim3(NT), sm, ST, (const float*)x, (const float*)dy, gbc, gbf, (float*)dx, dgbc, dgbf, B, F, T, C);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_fmean(const void* x, float* tok, int B, int F, int T, int C, int dtype, void* stream) {
+    int grid = grid_for((int64_t)B * T * C);
+    if (dtype) hipLaunchKernelGGL(fmean_kernel<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)x, tok, B, F, T, C);
+    else hipLaunchKernelGGL(fmean_kernel<float>, dim3(grid), dim3(NT), 0, ST, (const float*)x, tok, B, F, T, C);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_bcat_fwd(const void* x, const float* enh, void* out, int B, int F, int T, int C, int dtype,
+                            void* stream) {
+    DTT_CHECK(C % ept_of(dtype) == 0, "dtt_bcat_fwd: C=%d", C);
+    int grid = grid_for((int64_t)B * F * T * (2 * C / ept_of(dtype)));
+    if (dtype) hipLaunchKernelGGL(bcat_fwd_kernel<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)x, enh, (bf16*)out, B, F, T, C);
+    else hipLaunchKernelGGL(bcat_fwd_kernel<float>, dim3(grid), dim3(NT), 0, ST, (const float*)x, enh, (float*)out, B, F, T, C);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_bcat_bwd(const void* dout, const float* dtok, void* dx, float* denh, int B, int F, int T, int C,
+                            int dtype, void* stream) {
+    int grid = grid_for((int64_t)B * T * C);
+    if (dtype) hipLaunchKernelGGL(bcat_bwd_kernel<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)dout, dtok, (bf16*)dx, denh, B, F, T, C);
+    else hipLaunchKernelGGL(bcat_bwd_kernel<float>, dim3(grid), dim3(NT), 0, ST, (const float*)dout, dtok, (float*)dx, denh, B, F, T, C);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}

@@ -8,37 +8,6 @@
 
 namespace {
 
-template <typename T> struct MM;
-template <> struct MM<bf16> {
-    static constexpr int EPT = 8;            // elements per 16 bytes
-    static constexpr int PAD = 8;            // LDS row pad (elements): 80-byte rows
-    // one 16-wide K chunk: a/b point at 8 contiguous k elements of this lane
-    static __device__ __forceinline__ void mma16(const bf16* a, const bf16* b, f32x16_t& acc) {
-        s16x8_t av = *reinterpret_cast<const s16x8_t*>(a);
-        s16x8_t bv = *reinterpret_cast<const s16x8_t*>(b);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av),
-                                                      __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
-    }
-};
-template <> struct MM<float> {
-    static constexpr int EPT = 4;
-    static constexpr int PAD = 4;            // 144-byte rows
-    static __device__ __forceinline__ void mma16(const float* a, const float* b, f32x16_t& acc) {
-        float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
-        float4 b0 = *reinterpret_cast<const float4*>(b), b1 = *reinterpret_cast<const float4*>(b + 4);
-        // lane half h holds k = 8h..8h+7; instruction j contracts k in {j, 8+j}: any
-        // k permutation is fine as long as A and B use the same one.
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
-    }
-};
-
 // conv tap geometry: source pixel of output pixel (fo,to) for tap (kh,kw)
 __device__ __forceinline__ bool conv_src(const DttGemm& p, int fo, int to, int tap, int& fi, int& ti) {
     int kh = tap / 3, kw = tap - kh * 3;
@@ -228,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DttGemm p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const T* bp = Bs + ((wn * TN + j) * 32 + lr) * LD + kofs;
-                    MM<T>::mma16(ap, bp, acc[i][j]);
+                    MM<T>::mma(MM<T>::ldfrag(ap), MM<T>::ldfrag(bp), acc[i][j]);
                 }
             }
         }

@@ -371,7 +371,7 @@ extern "C" int dtt_in_gelu_fwd(const void* y, const float* stats, void* z, int B
     const int ept = ept_of(dtype);
     DTT_CHECK(C % ept == 0 && Fz <= Fy && Tz <= Ty, "dtt_in_gelu_fwd: bad shape");
     int64_t total = (int64_t)B * Fz * Tz * (C / ept);
-    int grid = (int)min<int64_t>((total + NT - 1) / NT, 8192);
+    int grid = (int)(((total + NT - 1) / NT) < 8192 ? ((total + NT - 1) / NT) : 8192);
     if (dtype) hipLaunchKernelGGL(in_gelu_fwd<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)y, stats, (bf16*)z, B, Fy, Ty, Fz, Tz, C);
     else hipLaunchKernelGGL(in_gelu_fwd<float>, dim3(grid), dim3(NT), 0, ST, (const float*)y, stats, (float*)z, B, Fy, Ty, Fz, Tz, C);
     DTT_LAUNCH_CHECK();
@@ -390,7 +390,7 @@ extern "C" int dtt_in_gelu_bwd(const void* y, const void* dz, const float* stats
     else hipLaunchKernelGGL(in_gelu_bwd_partial<float>, dim3(nch, B), dim3(NT), sm, ST, (const float*)y, (const float*)dz, stats, partial, Fy, Ty, Fz, Tz, C, chunk);
     hipLaunchKernelGGL(in_bwd_finalize, dim3((C + 127) / 128, B), dim3(128), 0, ST, partial, sums, C, nch, 1.f / (float)P);
     int64_t total = (int64_t)B * P * (C / ept);
-    int grid = (int)min<int64_t>((total + NT - 1) / NT, 8192);
+    int grid = (int)(((total + NT - 1) / NT) < 8192 ? ((total + NT - 1) / NT) : 8192);
     if (dtype) hipLaunchKernelGGL(in_gelu_bwd_apply<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)y, (const bf16*)dz, stats, sums, (bf16*)dy, B, Fy, Ty, Fz, Tz, C);
     else hipLaunchKernelGGL(in_gelu_bwd_apply<float>, dim3(grid), dim3(NT), 0, ST, (const float*)y, (const float*)dz, stats, sums, (float*)dy, B, Fy, Ty, Fz, Tz, C);
     DTT_LAUNCH_CHECK();

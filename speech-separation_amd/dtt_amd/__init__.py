@@ -1,0 +1,9 @@
+"""dtt_amd: MI355X-native (gfx950) DTTNet separation forward + backward.
+
+Host side of libdtt_hip.so; mirrors the reference's model / loss / metric
+classes (see ../src for the reference's own import paths)."""
+from .model import DTTNetModel  # noqa: F401
+from .loss import DTTNetLoss, PITLossWrapper, DTTNetLossWrapper  # noqa: F401
+from .metrics import (SiSnr, SiSnrI, SiSnrPITTraining, SiSnrPITInference, SiSnrIPITTraining,  # noqa: F401
+                      SiSnrIPITInference)
+from .ops import stft_mag_phase  # noqa: F401

@@ -1,0 +1,66 @@
+"""Losses with the reference's API (src/loss/{dttnet_loss,pit_loss_wrapper,
+dttnet_loss_wrapper}.py) on the fused HIP PIT-L1 kernels."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import DttError
+
+
+def _stack_preds(preds, batch):
+    st = batch.get("_stacked_preds")
+    if st is not None and len(preds) == st[0].shape[0] and all(
+            p["audio"].data_ptr() == st[2][i].data_ptr() for i, p in enumerate(preds)):
+        return st
+    return (torch.stack([p["spectrogram"] for p in preds]), torch.stack([p["phase"] for p in preds]),
+            torch.stack([p["audio"] for p in preds]))
+
+
+def _pit_l1(sources, preds, batch, fixed):
+    pspec, pphase, paudio = _stack_preds(preds, batch)
+    if not pspec.is_cuda:
+        raise DttError("dtt_amd losses run on an MI355X only (no CPU path)")
+    src = ([s["spectrogram"] for s in sources] + [s["phase"] for s in sources] + [s["audio"] for s in sources])
+    item, permuts = ops.PitL1Loss.apply(pspec, pphase, paudio, fixed, *src)
+    return item, permuts
+
+
+class DTTNetLoss(nn.Module):
+    """Per-item L1 loss of one (prediction, target) pair -> [B]  (dttnet_loss.py:13-34)."""
+
+    def forward(self, audio_true, spectrogram_true, phase_true, audio_pred, spectrogram_pred, phase_pred):
+        item, _ = ops.PitL1Loss.apply(spectrogram_pred.unsqueeze(0), phase_pred.unsqueeze(0),
+                                      audio_pred.unsqueeze(0), True, spectrogram_true, phase_true, audio_true)
+        return item
+
+
+class PITLossWrapper(nn.Module):
+    """pit_loss_wrapper.py:7-71: min over source permutations, perm[pred] = source,
+    itertools order, first minimum wins; returns {"loss", "batch_permuts" (int64 [B,n])}.
+    The permutation search runs on the device (the reference builds it on the host)."""
+
+    def __init__(self, loss_function=None):
+        super().__init__()
+        self.loss_function = loss_function if loss_function is not None else DTTNetLoss()
+        if not isinstance(self.loss_function, DTTNetLoss):
+            raise DttError("PITLossWrapper is fused with DTTNetLoss; other base losses are not supported")
+
+    def forward(self, audio, sources, preds, **batch):
+        item, permuts = _pit_l1(sources, preds, batch, False)
+        return {"loss": item.mean(), "batch_permuts": permuts}
+
+
+class DTTNetLossWrapper(nn.Module):
+    """dttnet_loss_wrapper.py:7-62: fixed source order, identity permutation."""
+
+    def __init__(self, loss_function=None):
+        super().__init__()
+        self.loss_function = loss_function if loss_function is not None else DTTNetLoss()
+        if not isinstance(self.loss_function, DTTNetLoss):
+            raise DttError("DTTNetLossWrapper is fused with DTTNetLoss; other base losses are not supported")
+
+    def forward(self, audio, sources, preds, **batch):
+        item, permuts = _pit_l1(sources, preds, batch, True)
+        return {"loss": item.mean(), "batch_permuts": permuts}

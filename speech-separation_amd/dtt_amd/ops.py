@@ -1,0 +1,630 @@
+"""Autograd operators of the DTTNet path on top of libdtt_hip.so.
+
+Every tensor that flows between these operators is channels-last
+``[B, F, T, C]`` in the compute dtype (bf16 or fp32); parameters stay fp32 in
+the reference's own layouts (state_dict contract) and are re-packed per call.
+All heavy work is done by the HIP kernels; torch is used for allocation and
+for (tiny) weight re-layouts only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from ._lib import lib, check, stream_ptr, ptr, dtype_code, gemm_raw, DttError
+
+F32 = torch.float32
+
+
+def _dt(t):
+    return dtype_code(t.dtype)
+
+
+def _empty(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+# --------------------------------------------------------------------------- #
+# thin wrappers over the C entry points
+# --------------------------------------------------------------------------- #
+def conv_gemm(x, wp, bias, out, geom, res=None):
+    """Implicit-GEMM 3x3 conv: x [B,Fi,Ti,Ci] -> out [B,Fo,To,Co]; wp [Co][9*Ci]."""
+    Co = wp.shape[0]
+    M = geom["cB"] * geom["cFo"] * geom["cTo"]
+    kw = dict(A=x, B=wp, C=out, M=M, N=Co, K=9 * geom["cCi"], a_ms=0, a_ks=1, b_ks=1, b_ns=wp.shape[1],
+              c_ms=Co, c_ns=1, dtype=_dt(x), a_mode=1, **geom)
+    if bias is not None:
+        kw.update(bias=bias, bias_mode=1)
+    if res is not None:
+        kw.update(R=res, r_ms=Co, r_ns=1)
+    gemm_raw(**kw)
+
+
+def conv_wgrad(p_side, q_side, geom, M, N):
+    """dWp[m][tap][n] = sum_p P[p][m] * Q[src(p,tap)][n]; geom: cFo/cTo = P grid, cFi/cTi = Q grid."""
+    P = geom["cB"] * geom["cFo"] * geom["cTo"]
+    dwp = torch.zeros(M, 9, N, dtype=F32, device=p_side.device)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * 9
+    splitk = max(1, min(512, (2048 + tiles - 1) // tiles, (P + 255) // 256))
+    gemm_raw(A=p_side, B=q_side, C=dwp, M=M, N=N, K=P, batch=9, splitk=splitk, a_ms=1, a_ks=M, a_bs=0,
+             b_ks=N, b_ns=1, b_bs=0, c_ms=9 * N, c_ns=1, c_bs=N, dtype=_dt(p_side), atomic=1, out_f32=1,
+             b_mode=1, **geom)
+    return dwp
+
+
+def colsum(x2d, rows, width, ld=None):
+    """Deterministic column sums of a [rows][width] matrix -> fp32 [width]."""
+    ld = width if ld is None else ld
+    nch = int(max(1, min(1024, rows // 256)))
+    part = _empty((nch, width), F32, x2d.device)
+    check(lib().dtt_colsum(ptr(x2d), ptr(part), C.c_int64(rows), width, C.c_int64(ld), nch, _dt(x2d), stream_ptr()),
+          "dtt_colsum")
+    if nch == 1:
+        return part[0]
+    out = _empty((1, width), F32, x2d.device)
+    check(lib().dtt_colsum(ptr(part), ptr(out), C.c_int64(nch), width, C.c_int64(width), 1, 0, stream_ptr()),
+          "dtt_colsum")
+    return out[0]
+
+
+def _in_chunk(B, P):
+    nch = max(1, min(P // 64 if P >= 64 else 1, max(1, 2048 // B)))
+    return (P + nch - 1) // nch
+
+
+def in_stats(y, eps=1e-5):
+    B, Fy, Ty, Cc = y.shape
+    P = Fy * Ty
+    chunk = _in_chunk(B, P)
+    nch = (P + chunk - 1) // chunk
+    part = _empty((B, nch, Cc, 2), F32, y.device)
+    stats = _empty((B, Cc, 2), F32, y.device)
+    check(lib().dtt_in_stats(ptr(y), ptr(part), ptr(stats), B, P, Cc, chunk, C.c_float(eps), _dt(y), stream_ptr()),
+          "dtt_in_stats")
+    return stats
+
+
+def in_gelu_fwd(y, stats, Fz, Tz):
+    B, Fy, Ty, Cc = y.shape
+    z = _empty((B, Fz, Tz, Cc), y.dtype, y.device)
+    check(lib().dtt_in_gelu_fwd(ptr(y), ptr(stats), ptr(z), B, Fy, Ty, Fz, Tz, Cc, _dt(y), stream_ptr()),
+          "dtt_in_gelu_fwd")
+    return z
+
+
+def in_gelu_bwd(y, dz, stats):
+    B, Fy, Ty, Cc = y.shape
+    Fz, Tz = dz.shape[1], dz.shape[2]
+    P = Fy * Ty
+    chunk = _in_chunk(B, P)
+    nch = (P + chunk - 1) // chunk
+    part = _empty((B, nch, Cc, 2), F32, y.device)
+    sums = _empty((B, Cc, 2), F32, y.device)
+    dy = torch.empty_like(y)
+    check(lib().dtt_in_gelu_bwd(ptr(y), ptr(dz), ptr(stats), ptr(part), ptr(sums), ptr(dy), B, Fy, Ty, Fz, Tz, Cc,
+                                chunk, _dt(y), stream_ptr()), "dtt_in_gelu_bwd")
+    return dy
+
+
+def binary(op, a, b):
+    out = torch.empty_like(a)
+    check(lib().dtt_binary(op, ptr(a), ptr(b), ptr(out), C.c_int64(a.numel()), _dt(a), stream_ptr()), "dtt_binary")
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# conv3x3 (+ InstanceNorm + GELU)
+# --------------------------------------------------------------------------- #
+def _conv_geoms(kind, B, Fi, Ti, Ci, Co):
+    """kind: 's1' same conv, 'down' stride-2 conv, 'up' transposed conv (stride 2, pad 1, out pad 1)."""
+    if kind == "s1":
+        Fo, To = Fi, Ti
+        fwd = dict(cB=B, cFi=Fi, cTi=Ti, cCi=Ci, cFo=Fo, cTo=To, cstride=1, ctrans=0)
+        dgrad = dict(cB=B, cFi=Fo, cTi=To, cCi=Co, cFo=Fi, cTo=Ti, cstride=1, ctrans=0)
+        wg = dict(cB=B, cFi=Fi, cTi=Ti, cCi=Ci, cFo=Fo, cTo=To, cstride=1, ctrans=0)
+    elif kind == "down":
+        Fo, To = (Fi + 1) // 2, (Ti + 1) // 2
+        fwd = dict(cB=B, cFi=Fi, cTi=Ti, cCi=Ci, cFo=Fo, cTo=To, cstride=2, ctrans=0)
+        dgrad = dict(cB=B, cFi=Fo, cTi=To, cCi=Co, cFo=Fi, cTo=Ti, cstride=2, ctrans=1)
+        wg = dict(cB=B, cFi=Fi, cTi=Ti, cCi=Ci, cFo=Fo, cTo=To, cstride=2, ctrans=0)
+    elif kind == "up":
+        Fo, To = 2 * Fi, 2 * Ti
+        fwd = dict(cB=B, cFi=Fi, cTi=Ti, cCi=Ci, cFo=Fo, cTo=To, cstride=2, ctrans=1)
+        dgrad = dict(cB=B, cFi=Fo, cTi=To, cCi=Co, cFo=Fi, cTo=Ti, cstride=2, ctrans=0)
+        # wgrad: P side = x grid (Fi,Ti), Q side = dy grid (Fo,To) gathered with stride 2
+        wg = dict(cB=B, cFi=Fo, cTi=To, cCi=Co, cFo=Fi, cTo=Ti, cstride=2, ctrans=0)
+    else:
+        raise DttError(f"unknown conv kind {kind}")
+    return Fo, To, fwd, dgrad, wg
+
+
+def _pack_fwd(w, kind, dt):
+    if kind == "up":      # ConvTranspose2d weight [Ci, Co, 3, 3]
+        return w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
+
+
+def _pack_dgrad(w, kind, dt):
+    if kind == "s1":
+        return w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()
+    if kind == "down":
+        return w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()      # up: [Ci][tap][Co]
+
+
+def _conv_backward(kind, x, w, dy, need_dx):
+    """dy: gradient of the raw conv output [B,Fo,To,Co]. Returns dx, dw (param layout, fp32)."""
+    B, Fi, Ti, Ci = x.shape
+    Co = dy.shape[3]
+    _, _, _, gd, gw = _conv_geoms(kind, B, Fi, Ti, Ci, Co)
+    if kind == "up":
+        dwp = conv_wgrad(x, dy, gw, Ci, Co)                      # [Ci][9][Co]
+        dw = dwp.view(Ci, 3, 3, Co).permute(0, 3, 1, 2)
+    else:
+        dwp = conv_wgrad(dy, x, gw, Co, Ci)                      # [Co][9][Ci]
+        dw = dwp.view(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        conv_gemm(dy, _pack_dgrad(w, kind, x.dtype), None, dx, gd)
+    return dx, dw.contiguous()
+
+
+class ConvNormGelu(torch.autograd.Function):
+    """conv3x3 -> InstanceNorm2d(affine=False, eps 1e-5) -> exact GELU (-> crop).
+    Reference: block_tfc_tdf.py:12-17, block_sampling.py:8-12,23-28, decoder.py:46-52."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, kind, crop):
+        B, Fi, Ti, Ci = x.shape
+        Co = w.shape[1] if kind == "up" else w.shape[0]
+        Fo, To, gf, _, _ = _conv_geoms(kind, B, Fi, Ti, Ci, Co)
+        y = _empty((B, Fo, To, Co), x.dtype, x.device)
+        conv_gemm(x, _pack_fwd(w, kind, x.dtype), b, y, gf)
+        stats = in_stats(y)
+        Fz, Tz = (Fo, To) if crop is None else crop
+        z = in_gelu_fwd(y, stats, Fz, Tz)
+        ctx.save_for_backward(x, w, y, stats)
+        ctx.kind = kind
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, y, stats = ctx.saved_tensors
+        dy = in_gelu_bwd(y, dz.contiguous(), stats)
+        dx, dw = _conv_backward(ctx.kind, x, w, dy, ctx.needs_input_grad[0])
+        # the bias feeds an affine-free InstanceNorm: its gradient is identically zero
+        db = torch.zeros(w.shape[1] if ctx.kind == "up" else w.shape[0], dtype=F32, device=x.device)
+        return dx, dw, db, None, None
+
+
+class ConvAdd(torch.autograd.Function):
+    """skip_conv(x) + h  (block_tfc_tdf.py:41,46): conv3x3 with bias and a fused residual add."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, h):
+        B, Fi, Ti, Ci = x.shape
+        Co = w.shape[0]
+        _, _, gf, _, _ = _conv_geoms("s1", B, Fi, Ti, Ci, Co)
+        y = _empty((B, Fi, Ti, Co), x.dtype, x.device)
+        conv_gemm(x, _pack_fwd(w, "s1", x.dtype), b, y, gf, res=h)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx, dw = _conv_backward("s1", x, w, dy, ctx.needs_input_grad[0])
+        Co = dy.shape[3]
+        db = colsum(dy, dy.numel() // Co, Co)
+        return dx, dw, db, dy
+
+
+# --------------------------------------------------------------------------- #
+# TDF: two Linears on the frequency axis + residual (block_tfc_tdf.py:23-26,43-44)
+# --------------------------------------------------------------------------- #
+class TDF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        B, Fq, T, Cc = x.shape
+        J = w1.shape[0]
+        N = T * Cc
+        dt = x.dtype
+        Fp = (Fq + 7) // 8 * 8
+        w1p = torch.zeros(J, Fp, dtype=dt, device=x.device)
+        w1p[:, :Fq] = w1
+        w2p = w2.to(dt).contiguous()                        # [F][J]
+        hid = _empty((B, J, N), dt, x.device)
+        gemm_raw(A=w1p, B=x, C=hid, bias=b1, M=J, N=N, K=Fq, batch=B, a_ms=Fp, a_ks=1, a_bs=0, b_ks=N, b_ns=1,
+                 b_bs=Fq * N, c_ms=N, c_ns=1, c_bs=J * N, dtype=_dt(x), bias_mode=2)
+        out = torch.empty_like(x)
+        gemm_raw(A=w2p, B=hid, C=out, bias=b2, R=x, M=Fq, N=N, K=J, batch=B, a_ms=J, a_ks=1, a_bs=0, b_ks=N,
+                 b_ns=1, b_bs=J * N, c_ms=N, c_ns=1, c_bs=Fq * N, r_ms=N, r_ns=1, r_bs=Fq * N, dtype=_dt(x),
+                 bias_mode=2)
+        ctx.save_for_backward(x, hid, w1p, w2p)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, hid, w1p, w2p = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, Fq, T, Cc = x.shape
+        J, Fp = w1p.shape
+        N = T * Cc
+        d = _dt(x)
+        dev = x.device
+        dhid = torch.empty_like(hid)
+        gemm_raw(A=w2p, B=dout, C=dhid, M=J, N=N, K=Fq, batch=B, a_ms=1, a_ks=J, a_bs=0, b_ks=N, b_ns=1,
+                 b_bs=Fq * N, c_ms=N, c_ns=1, c_bs=J * N, dtype=d)
+        dx = torch.empty_like(x)
+        gemm_raw(A=w1p, B=dhid, C=dx, R=dout, M=Fq, N=N, K=J, batch=B, a_ms=1, a_ks=Fp, a_bs=0, b_ks=N, b_ns=1,
+                 b_bs=J * N, c_ms=N, c_ns=1, c_bs=Fq * N, r_ms=N, r_ns=1, r_bs=Fq * N, dtype=d)
+        sk = max(1, min(64, N // 512, max(1, 1024 // B)))
+        dw2 = torch.zeros(Fq, J, dtype=F32, device=dev)
+        gemm_raw(A=dout, B=hid, C=dw2, M=Fq, N=J, K=N, batch=B, splitk=sk, a_ms=N, a_ks=1, a_bs=Fq * N, b_ks=1,
+                 b_ns=N, b_bs=J * N, c_ms=J, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
+        dw1 = torch.zeros(J, Fq, dtype=F32, device=dev)
+        gemm_raw(A=dhid, B=x, C=dw1, M=J, N=Fq, K=N, batch=B, splitk=sk, a_ms=N, a_ks=1, a_bs=J * N, b_ks=1,
+                 b_ns=N, b_bs=Fq * N, c_ms=Fq, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
+        ones = torch.ones(N, dtype=x.dtype, device=dev)
+        db2 = torch.zeros(Fq, dtype=F32, device=dev)
+        gemm_raw(A=dout, B=ones, C=db2, M=Fq, N=1, K=N, batch=B, a_ms=N, a_ks=1, a_bs=Fq * N, b_ks=1, b_ns=0,
+                 b_bs=0, c_ms=1, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
+        db1 = torch.zeros(J, dtype=F32, device=dev)
+        gemm_raw(A=dhid, B=ones, C=db1, M=J, N=1, K=N, batch=B, a_ms=N, a_ks=1, a_bs=J * N, b_ks=1, b_ns=0,
+                 b_bs=0, c_ms=1, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
+        return dx, dw1, db1, dw2, db2
+
+
+# --------------------------------------------------------------------------- #
+# TC_FC_RNN: GroupNorm -> BiLSTM -> Linear -> + x   (latent.py:77-104)
+# --------------------------------------------------------------------------- #
+def _pack_whh_fwd(w, dt):
+    """[4H, H] -> MFMA B-fragment order [4H/32][H/16][64 lanes][8]."""
+    G4, H = w.shape
+    return w.view(G4 // 32, 32, H // 16, 2, 8).permute(0, 2, 3, 1, 4).to(dt).contiguous()
+
+
+def _pack_whh_bwd(w, dt):
+    """[4H, H] -> fragments of B[k][n] = W_hh[k][n] for dh = dG * W_hh: [H/32][4H/16][64][8]."""
+    G4, H = w.shape
+    return w.view(G4 // 16, 2, 8, H // 32, 32).permute(3, 0, 1, 4, 2).to(dt).contiguous()
+
+
+class DualPathRNN(torch.autograd.Function):
+    """One TC_FC_RNN over the time axis (along_f=False) or the frequency axis
+    (along_f=True) of x [B,F,T,C], heads folded into the sequence batch.
+    The frequency variant returns its result in [B,T,F,C] memory order, which
+    the caller re-views as [B,F,T,C]: that is the reference's merge_heads
+    (latent.py:68-74), which views without permuting back."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, fc_w, fc_b, heads,
+                along_f):
+        B, Fq, T, Cc = x.shape
+        Cp = Cc // heads
+        H = w_hh.shape[1]
+        dt, dev, d = x.dtype, x.device, _dt(x)
+        if along_f:
+            nslab, NI, L, OS, IS, RS = B * T, T, Fq, Fq * T * Cc, Cc, T * Cc
+        else:
+            nslab, NI, L, OS, IS, RS = B * Fq, 1, T, T * Cc, 0, Cc
+        gs = 16 if Cp % 16 == 0 else Cp
+        ng = Cc // gs
+        R = nslab * L * heads
+        xn = _empty((nslab, L, Cc), dt, dev)
+        xperm = _empty((nslab, L, Cc), dt, dev) if along_f else None
+        gstats = _empty((nslab, ng, 2), F32, dev)
+        geo = (nslab, NI, L, Cc, Cp, gs, C.c_int64(OS), C.c_int64(IS), C.c_int64(RS))
+        check(lib().dtt_gn_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(xn), ptr(xperm), ptr(gstats), *geo,
+                               C.c_float(1e-5), d, stream_ptr()), "dtt_gn_fwd")
+        # input projection, both directions: xg [R][2][4H]
+        wih = torch.cat([w_ih, w_ih_r], 0).to(dt).contiguous()                 # [8H][Cp]
+        bsum = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r]).contiguous()
+        xg = _empty((R, 8 * H), dt, dev)
+        gemm_raw(A=xn, B=wih, C=xg, bias=bsum, M=R, N=8 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=1, b_ns=Cp,
+                 c_ms=8 * H, c_ns=1, dtype=d, bias_mode=1)
+        wp = torch.stack([_pack_whh_fwd(w_hh, dt), _pack_whh_fwd(w_hh_r, dt)]).contiguous()
+        y = _empty((R, 2 * H), dt, dev)
+        need = any(ctx.needs_input_grad)
+        gates = _empty((R, 2, 4 * H), dt, dev) if need else None
+        cst = _empty((R, 2, H), F32, dev) if need else None
+        N = nslab * heads
+        check(lib().dtt_lstm_fwd(ptr(xg), ptr(wp), ptr(y), ptr(gates), ptr(cst), N, L, heads, H, d, stream_ptr()),
+              "dtt_lstm_fwd")
+        fcw = fc_w.to(dt).contiguous()                                         # [Cp][4Cp]
+        res = xperm if along_f else x
+        out = _empty((nslab, L, Cc), dt, dev)
+        gemm_raw(A=y, B=fcw, C=out, bias=fc_b, R=res, M=R, N=Cp, K=2 * H, a_ms=2 * H, a_ks=1, b_ks=1, b_ns=2 * H,
+                 c_ms=Cp, c_ns=1, r_ms=Cp, r_ns=1, dtype=d, bias_mode=1)
+        ctx.save_for_backward(x, gamma, xn, gstats, wih, w_hh, w_hh_r, y, gates, cst, fcw)
+        ctx.cfg = (heads, along_f, geo, gs)
+        # along_f: memory order is [B,T,F,C]; the view below is the reference's merge_heads quirk
+        return out.view(B, Fq, T, Cc)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, xn, gstats, wih, w_hh, w_hh_r, y, gates, cst, fcw = ctx.saved_tensors
+        heads, along_f, geo, gs = ctx.cfg
+        nslab, NI, L, Cc, Cp = geo[0], geo[1], geo[2], geo[3], geo[4]
+        dt, dev, d = x.dtype, x.device, _dt(x)
+        H = w_hh.shape[1]
+        R = nslab * L * heads
+        dout = dout.contiguous()                       # memory order == rows (outer, step, head)
+        # Linear backward
+        dy = _empty((R, 2 * H), dt, dev)
+        gemm_raw(A=dout, B=fcw, C=dy, M=R, N=2 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=2 * H, b_ns=1, c_ms=2 * H, c_ns=1,
+                 dtype=d)
+        sk = max(1, min(256, R // 1024))
+        dfcw = torch.zeros(Cp, 2 * H, dtype=F32, device=dev)
+        gemm_raw(A=dout, B=y, C=dfcw, M=Cp, N=2 * H, K=R, splitk=sk, a_ms=1, a_ks=Cp, b_ks=2 * H, b_ns=1,
+                 c_ms=2 * H, c_ns=1, dtype=d, atomic=1, out_f32=1)
+        dfcb = colsum(dout, R, Cp)
+        # recurrent backward
+        wpt = torch.stack([_pack_whh_bwd(w_hh, dt), _pack_whh_bwd(w_hh_r, dt)]).contiguous()
+        dG = _empty((R, 2, 4 * H), dt, dev)
+        check(lib().dtt_lstm_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), nslab * heads, L, heads, H, d,
+                                 stream_ptr()), "dtt_lstm_bwd")
+        G4 = 4 * H
+        dwhh = []
+        for di, (shift, edge) in enumerate(((-heads, 0), (heads, L - 1))):
+            g = torch.zeros(G4, H, dtype=F32, device=dev)
+            gemm_raw(A=dG[:, di], B=y[:, di * H:], C=g, M=G4, N=H, K=R, splitk=sk, a_ms=1, a_ks=2 * G4, b_ks=2 * H,
+                     b_ns=1, c_ms=H, c_ns=1, dtype=d, atomic=1, out_f32=1, b_mode=2, sh_shift=shift,
+                     sh_heads=heads, sh_L=L, sh_edge=edge)
+            dwhh.append(g)
+        dwih = torch.zeros(2 * G4, Cp, dtype=F32, device=dev)
+        gemm_raw(A=dG, B=xn, C=dwih, M=2 * G4, N=Cp, K=R, splitk=sk, a_ms=1, a_ks=2 * G4, b_ks=Cp, b_ns=1,
+                 c_ms=Cp, c_ns=1, dtype=d, atomic=1, out_f32=1)
+        dbias = colsum(dG, R, 2 * G4)
+        dxn = _empty((nslab, L, Cc), dt, dev)
+        gemm_raw(A=dG, B=wih, C=dxn, M=R, N=Cp, K=2 * G4, a_ms=2 * G4, a_ks=1, b_ks=Cp, b_ns=1, c_ms=Cp, c_ns=1,
+                 dtype=d)
+        dx = torch.empty_like(x)
+        pgb = _empty((nslab, Cc, 2), F32, dev)
+        check(lib().dtt_gn_bwd(ptr(x), ptr(dxn), ptr(dout), ptr(gamma), ptr(gstats), ptr(dx), ptr(pgb), *geo, d,
+                               stream_ptr()), "dtt_gn_bwd")
+        gb = colsum(pgb, nslab * heads, Cp * 2).view(Cp, 2)
+        db_f, db_r = dbias[:G4], dbias[G4:]
+        return (dx, gb[:, 0].contiguous(), gb[:, 1].contiguous(), dwih[:G4], dwhh[0], db_f, db_f, dwih[G4:],
+                dwhh[1], db_r, db_r, dfcw, dfcb, None, None)
+
+
+# --------------------------------------------------------------------------- #
+# elementwise
+# --------------------------------------------------------------------------- #
+class MulSkip(torch.autograd.Function):
+    """out = a * skip  (decoder.py:43)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return binary(1, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        return binary(1, g, b), binary(1, g, a)
+
+
+class InitConv(torch.autograd.Function):
+    """stack([spec, phase], 1) -> 1x1 conv (encoder.py:26-27), planar fp32 in, channels-last out."""
+
+    @staticmethod
+    def forward(ctx, spec, phase, w, b, dt):
+        B, Fq, T = spec.shape
+        Cc = w.shape[0]
+        spec = spec.contiguous().float()
+        phase = phase.contiguous().float()
+        out = _empty((B, Fq, T, Cc), dt, spec.device)
+        w2 = w.reshape(Cc, 2).contiguous()
+        check(lib().dtt_init_conv_fwd(ptr(spec), ptr(phase), ptr(w2), ptr(b), ptr(out), C.c_int64(B * Fq * T), Cc,
+                                      dtype_code(dt), stream_ptr()), "dtt_init_conv_fwd")
+        ctx.save_for_backward(spec, phase)
+        ctx.wshape = w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        spec, phase = ctx.saved_tensors
+        dout = dout.contiguous()
+        Cc = dout.shape[3]
+        P = spec.numel()
+        nch = int(max(1, min(1024, P // 256)))
+        part = _empty((nch, Cc * 3), F32, spec.device)
+        check(lib().dtt_init_conv_bwd(ptr(spec), ptr(phase), ptr(dout), ptr(part), C.c_int64(P), Cc, nch, _dt(dout),
+                                      stream_ptr()), "dtt_init_conv_bwd")
+        s = colsum(part, nch, Cc * 3).view(Cc, 3)
+        return None, None, s[:, :2].reshape(ctx.wshape).contiguous(), s[:, 2].contiguous(), None
+
+
+# --------------------------------------------------------------------------- #
+# STFT / iSTFT (DFT as GEMM)
+# --------------------------------------------------------------------------- #
+_BASIS = {}
+
+
+def _ld(n_fft):
+    Fq = n_fft // 2 + 1
+    imoff = (Fq + 7) // 8 * 8
+    return Fq, imoff, 2 * imoff
+
+
+def dft_bases(n_fft, dev):
+    """fp32 forward (Hann-windowed) and inverse real-DFT bases, rows = output index."""
+    key = (n_fft, str(dev))
+    if key not in _BASIS:
+        Fq, imoff, ld = _ld(n_fft)
+        n = torch.arange(n_fft, dtype=torch.float64)
+        k = torch.arange(Fq, dtype=torch.float64)
+        ang = 2.0 * math.pi * torch.outer(k, n) / n_fft                       # [F][n]
+        win = 0.5 - 0.5 * torch.cos(2.0 * math.pi * n / n_fft)
+        fwd = torch.zeros(ld, n_fft, dtype=torch.float64)                      # [col][n]
+        fwd[:Fq] = torch.cos(ang) * win
+        fwd[imoff:imoff + Fq] = -torch.sin(ang) * win
+        wk = torch.full((Fq,), 2.0, dtype=torch.float64)
+        wk[0] = 1.0
+        wk[-1] = 1.0
+        inv = torch.zeros(n_fft, ld, dtype=torch.float64)                      # [n][k]
+        inv[:, :Fq] = (torch.cos(ang) * wk[:, None] / n_fft).t()
+        im = (-torch.sin(ang) * wk[:, None] / n_fft).t()
+        im[:, 0] = 0.0
+        im[:, -1] = 0.0
+        inv[:, imoff:imoff + Fq] = im
+        _BASIS[key] = (fwd.float().to(dev).contiguous(), inv.float().to(dev).contiguous())
+    return _BASIS[key]
+
+
+def stft_mag_phase(x, n_fft=1024, hop=256):
+    """GPU STFT front end (replaces torchaudio Spectrogram + abs/angle in the data
+    loader, base_dataset.py:154-167).  Exact-fp32 MFMA DFT GEMM.  x [B,L] -> mag, phase [B,F,T]."""
+    x = x.contiguous().float()
+    B, L = x.shape
+    Fq, imoff, ld = _ld(n_fft)
+    pad = n_fft // 2
+    Lp = L + 2 * pad
+    T = 1 + L // hop
+    fwd, _ = dft_bases(n_fft, x.device)
+    xp = _empty((B, Lp), F32, x.device)
+    check(lib().dtt_reflect_pad(ptr(x), ptr(xp), B, L, pad, stream_ptr()), "dtt_reflect_pad")
+    reim = _empty((B, T, ld), F32, x.device)
+    gemm_raw(A=xp, B=fwd, C=reim, M=T, N=ld, K=n_fft, batch=B, a_ms=hop, a_ks=1, a_bs=Lp, b_ks=1, b_ns=n_fft,
+             b_bs=0, c_ms=ld, c_ns=1, c_bs=T * ld, dtype=0)
+    mag = _empty((B, Fq, T), F32, x.device)
+    phase = _empty((B, Fq, T), F32, x.device)
+    check(lib().dtt_stft_post(ptr(reim), ptr(mag), ptr(phase), B, Fq, T, ld, imoff, stream_ptr()), "dtt_stft_post")
+    return mag, phase
+
+
+class MaskISTFT(torch.autograd.Function):
+    """out_conv (1x1, C -> 2S) + complex-style mask + torch.polar + rectangular iSTFT
+    (decoder.py:29, model_dttnet.py:47-85).  Returns pspec, pphase [S,B,F,T], audio [S,B,L] (fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, mspec, mphase, S, n_fft, hop, length):
+        B, Fq, T, Cc = x.shape
+        dev, dt, d = x.device, x.dtype, _dt(x)
+        Fq2, imoff, ld = _ld(n_fft)
+        if Fq2 != Fq:
+            raise DttError(f"mask: F={Fq} does not match n_fft={n_fft}")
+        mspec = mspec.contiguous().float()
+        mphase = mphase.contiguous().float()
+        w2 = w.reshape(2 * S, Cc).contiguous()
+        pspec = _empty((S, B, Fq, T), F32, dev)
+        pphase = _empty((S, B, Fq, T), F32, dev)
+        Z = torch.zeros(S * B, T, ld, dtype=dt, device=dev)
+        check(lib().dtt_mask_fwd(ptr(x), ptr(w2), ptr(b), ptr(mspec), ptr(mphase), ptr(pspec), ptr(pphase), ptr(Z),
+                                 B, Fq, T, Cc, S, ld, imoff, d, stream_ptr()), "dtt_mask_fwd")
+        _, inv = dft_bases(n_fft, dev)
+        invt = inv.to(dt)
+        frames = _empty((S * B * T, n_fft), F32, dev)
+        gemm_raw(A=Z, B=invt, C=frames, M=S * B * T, N=n_fft, K=ld, a_ms=ld, a_ks=1, b_ks=1, b_ns=ld, c_ms=n_fft,
+                 c_ns=1, dtype=d, out_f32=1)
+        audio = _empty((S, B, length), F32, dev)
+        check(lib().dtt_ola_fwd(ptr(frames), ptr(audio), S * B, T, n_fft, hop, length, stream_ptr()), "dtt_ola_fwd")
+        ctx.save_for_backward(x, w2, mspec, mphase, pspec, pphase, invt)
+        ctx.cfg = (S, n_fft, hop, length, w.shape)
+        return pspec, pphase, audio
+
+    @staticmethod
+    def backward(ctx, dspec, dphase, daudio):
+        x, w2, mspec, mphase, pspec, pphase, invt = ctx.saved_tensors
+        S, n_fft, hop, length, wshape = ctx.cfg
+        B, Fq, T, Cc = x.shape
+        dev, dt, d = x.device, x.dtype, _dt(x)
+        _, imoff, ld = _ld(n_fft)
+        Lp = n_fft + hop * (T - 1)
+        daudio = daudio.contiguous().float()
+        gpad = _empty((S * B, Lp), dt, dev)
+        check(lib().dtt_ola_bwd(ptr(daudio), ptr(gpad), S * B, T, n_fft, hop, length, d, stream_ptr()), "dtt_ola_bwd")
+        dZ = _empty((S * B, T, ld), F32, dev)
+        gemm_raw(A=gpad, B=invt, C=dZ, M=T, N=ld, K=n_fft, batch=S * B, a_ms=hop, a_ks=1, a_bs=Lp, b_ks=ld, b_ns=1,
+                 b_bs=0, c_ms=ld, c_ns=1, c_bs=T * ld, dtype=d, out_f32=1)
+        dx = torch.empty_like(x)
+        dmask = _empty((B * Fq * T, 2 * S), dt, dev)
+        check(lib().dtt_mask_bwd(ptr(w2), ptr(mspec), ptr(mphase), ptr(pspec), ptr(pphase),
+                                 ptr(dspec.contiguous().float()), ptr(dphase.contiguous().float()), ptr(dZ), ptr(dx),
+                                 ptr(dmask), B, Fq, T, Cc, S, ld, imoff, d, stream_ptr()), "dtt_mask_bwd")
+        P = B * Fq * T
+        dw = torch.zeros(2 * S, Cc, dtype=F32, device=dev)
+        gemm_raw(A=dmask, B=x, C=dw, M=2 * S, N=Cc, K=P, splitk=max(1, min(512, P // 2048)), a_ms=1, a_ks=2 * S,
+                 b_ks=Cc, b_ns=1, c_ms=Cc, c_ns=1, dtype=d, atomic=1, out_f32=1)
+        db = colsum(dmask, P, 2 * S)
+        return dx, dw.view(wshape), db, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# PIT L1 loss and SI-SNR
+# --------------------------------------------------------------------------- #
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+class PitL1Loss(torch.autograd.Function):
+    """DTTNetLoss under PITLossWrapper / DTTNetLossWrapper (dttnet_loss.py:28-34,
+    pit_loss_wrapper.py:41-71, dttnet_loss_wrapper.py:41-62).  Permutation search on the
+    device: no host sync.  Returns the per-item losses [B] and batch_permuts [B,S]."""
+
+    @staticmethod
+    def forward(ctx, pspec, pphase, paudio, fixed, *src):
+        S, B = pspec.shape[0], pspec.shape[1]
+        dev = pspec.device
+        pspec, pphase, paudio = pspec.contiguous().float(), pphase.contiguous().float(), paudio.contiguous().float()
+        src = [s.contiguous().float() for s in src]
+        sspec, sphase, saudio = src[:S], src[S:2 * S], src[2 * S:]
+        FT = pspec.shape[2] * pspec.shape[3]
+        L = paudio.shape[2]
+        nc_sp = int(max(1, min(64, FT // 4096)))
+        nc_au = int(max(1, min(64, L // 4096)))
+        p_sp = _empty((B, nc_sp, S * S), F32, dev)
+        p_ph = _empty((B, nc_sp, S * S), F32, dev)
+        p_au = _empty((B, nc_au, S * S), F32, dev)
+        st = stream_ptr()
+        check(lib().dtt_l1_pairs(ptr(pspec), _ptr_array(sspec), ptr(p_sp), S, B, C.c_int64(FT), nc_sp, st), "dtt_l1_pairs")
+        check(lib().dtt_l1_pairs(ptr(pphase), _ptr_array(sphase), ptr(p_ph), S, B, C.c_int64(FT), nc_sp, st), "dtt_l1_pairs")
+        check(lib().dtt_l1_pairs(ptr(paudio), _ptr_array(saudio), ptr(p_au), S, B, C.c_int64(L), nc_au, st), "dtt_l1_pairs")
+        item = _empty((B,), F32, dev)
+        permuts = _empty((B, S), torch.int64, dev)
+        loss = _empty((), F32, dev)
+        check(lib().dtt_pit_select(ptr(p_sp), ptr(p_ph), ptr(p_au), nc_sp, nc_au, C.c_int64(FT), C.c_int64(L), S, B,
+                                   1 if fixed else 0, ptr(item), ptr(permuts), ptr(loss), st), "dtt_pit_select")
+        ctx.save_for_backward(pspec, pphase, paudio, permuts, *src)
+        ctx.mark_non_differentiable(permuts)
+        return item, permuts
+
+    @staticmethod
+    def backward(ctx, gloss, _gp):
+        pspec, pphase, paudio, permuts, *src = ctx.saved_tensors
+        S, B = pspec.shape[0], pspec.shape[1]
+        FT = pspec.shape[2] * pspec.shape[3]
+        L = paudio.shape[2]
+        gloss = gloss.contiguous().float().reshape(B)          # per-item upstream gradient
+        st = stream_ptr()
+        outs = []
+        for pred, srcs, n in ((pspec, src[:S], FT), (pphase, src[S:2 * S], FT), (paudio, src[2 * S:], L)):
+            dp = torch.empty_like(pred)
+            check(lib().dtt_l1_bwd(ptr(pred), _ptr_array(srcs), ptr(permuts), ptr(gloss), C.c_float(1.0 / n),
+                                   ptr(dp), S, B, C.c_int64(n), st), "dtt_l1_bwd")
+            outs.append(dp)
+        return (outs[0], outs[1], outs[2], None) + (None,) * len(src)
+
+
+def si_snr_matrix(est, sources, eps=1e-5):
+    """est [E,B,L] fp32, sources: list of S [B,L] -> SI-SNR [E,S,B] (si_snr.py:26-34)."""
+    est = est.contiguous().float()
+    sources = [s.contiguous().float() for s in sources]
+    E, B, L = est.shape
+    S = len(sources)
+    nch = int(max(1, min(32, L // 2048)))
+    dev = est.device
+    part = _empty((E * S * B * nch * 2,), F32, dev)
+    alpha = _empty((E * S * B,), F32, dev)
+    out = _empty((E, S, B), F32, dev)
+    check(lib().dtt_sisnr(ptr(est), _ptr_array(sources), ptr(part), ptr(alpha), ptr(out), E, S, B, C.c_int64(L), nch,
+                          C.c_float(eps), stream_ptr()), "dtt_sisnr")
+    return out

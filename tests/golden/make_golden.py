@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
-from oracle.fill import fill_tensor, weight_checksum, synth_sources, synth_video  # noqa: E402
+from oracle.fill import fill_tensor, weight_checksum, synth_sources, synth_video, stable_stft  # noqa: E402
 
 
 def _install_reference():
@@ -72,10 +72,12 @@ def torch_stft(x, n_fft, hop):
 def make_batch(B, L, n_fft, hop, seed):
     s1, s2 = synth_sources(B, L, seed)
     mix = s1 + s2
-    spec, phase = torch_stft(mix, n_fft, hop)
+    # model inputs: machine-portable STFT features (oracle/fill.py:stable_stft); the
+    # torch.stft known-answer vectors live in stft_kat.npz
+    spec, phase = stable_stft(mix, n_fft, hop)
     sources = []
     for s in (s1, s2):
-        sp, ph = torch_stft(s, n_fft, hop)
+        sp, ph = stable_stft(s, n_fft, hop)
         sources.append({"audio": s, "spectrogram": sp, "phase": ph})
     return {"audio": mix, "spectrogram": spec, "phase": phase, "sources": sources,
             "audio_length": L}

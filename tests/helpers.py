@@ -3,16 +3,16 @@ golden generator (tests/golden/make_golden.py) fed to the reference."""
 import torch
 
 import oracle
-from oracle.fill import fill_state_dict, synth_sources, weight_checksum  # noqa: F401
+from oracle.fill import fill_state_dict, synth_sources, weight_checksum, stable_stft  # noqa: F401
 
 
 def make_batch(B, L, n_fft, hop, seed):
     s1, s2 = synth_sources(B, L, seed)
     mix = s1 + s2
-    spec, phase = oracle.stft_mag_phase(mix, n_fft, hop)
+    spec, phase = stable_stft(mix, n_fft, hop)
     sources = []
     for s in (s1, s2):
-        sp, ph = oracle.stft_mag_phase(s, n_fft, hop)
+        sp, ph = stable_stft(s, n_fft, hop)
         sources.append({"audio": s, "spectrogram": sp, "phase": ph})
     return {"audio": mix, "spectrogram": spec, "phase": phase, "sources": sources,
             "audio_length": L}

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the DTTNet separation training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = STFT of the mixture and both sources (GPU DFT GEMM) -> model
+forward -> PIT-L1 loss -> backward (-> bucketed RCCL gradient all-reduce when
+N > 1) -> gradient clip -> AdamW step, on one batch of synthetic 2-speaker
+16 kHz mixtures that is already resident in HBM.  Weak scaling: the per-GPU
+batch is fixed.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "speech-separation_amd"))
+sys.path.insert(0, ROOT)
+
+SR = 16000
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: DTTNet audio-only 15M training step, B=64 x 2 s bf16
+    "audio15m": dict(model="audio", g=32, n_idp=4, batch=64, seconds=2.0, fwd_gflop_per_item=96.6),
+}
+
+
+def synth_batch(B, L, seed, dev):
+    """Band-limited, slowly modulated noise sources, peak 0.3, generated on the GPU."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    t = torch.arange(L, device=dev, dtype=torch.float32) / SR
+    srcs = []
+    f = torch.fft.rfftfreq(L, 1.0 / SR).to(dev)
+    band = (1.0 / (1.0 + (80.0 / f.clamp(min=1e-3)) ** 8) / (1.0 + (f / 7000.0) ** 8)).sqrt()
+    for _ in range(2):
+        w = torch.randn(B, L, generator=g, device=dev)
+        s = torch.fft.irfft(torch.fft.rfft(w, dim=-1) * band, n=L, dim=-1)
+        rate = 2.0 + 6.0 * torch.rand(B, 1, generator=g, device=dev)
+        ph = 6.2831853 * torch.rand(B, 1, generator=g, device=dev)
+        s = s * (0.5 - 0.5 * torch.cos(6.2831853 * rate * t.unsqueeze(0) + ph))
+        srcs.append((0.3 * s / s.abs().amax(dim=-1, keepdim=True).clamp(min=1e-9)).contiguous())
+    return srcs
+
+
+def cpu_baseline(cfg, n_fft, hop, L, seconds_budget=20.0):
+    """The oracle (CPU restatement of the reference, oracle/dtt_oracle.py) timed on this host:
+    forward + PIT-L1 loss + backward, fp32, on a bounded sample (B=2) of the same workload."""
+    import oracle
+    from oracle.fill import synth_sources
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    import dtt_amd
+    m = dtt_amd.DTTNetModel(g=cfg["g"], n_sources=2, n_layers=3, n_idp_layers=cfg["n_idp"], n_fft=n_fft,
+                            hop_length=hop, n_heads=2)
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    B = 2
+    s1, s2 = synth_sources(B, L, seed=1)
+    mix = s1 + s2
+
+    def step():
+        spec, phase = oracle.stft_mag_phase(mix, n_fft, hop)
+        sources = []
+        for s in (s1, s2):
+            sp, ph = oracle.stft_mag_phase(s, n_fft, hop)
+            sources.append({"audio": s, "spectrogram": sp, "phase": ph})
+        out = oracle.dttnet_forward(sd, spec, phase, L, n_fft=n_fft, hop=hop)
+        r = oracle.pit_loss(mix, sources, out["preds"])
+        r["loss"].backward()
+        for v in sd.values():
+            v.grad = None
+
+    step()
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < seconds_budget and n < 10):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B * L / SR / dt, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32 fwd+PIT-L1+bwd, B={B} x {L / SR:.0f} s, {n} iterations after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="audio15m", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import dtt_amd
+    from dtt_amd.dist import GradBucketReducer
+
+    cfg = dict(WORKLOADS[args.workload])
+    B = args.batch or cfg["batch"]
+    n_fft, hop = 1024, 256
+    L = int(cfg["seconds"] * SR)
+
+    torch.manual_seed(1)                       # train.yaml:56; same weights on every rank
+    model = dtt_amd.DTTNetModel(g=cfg["g"], n_sources=2, n_layers=3, n_idp_layers=cfg["n_idp"], n_fft=n_fft,
+                                hop_length=hop, n_heads=2, use_checkpoints=True, precision=args.precision).to(dev)
+    criterion = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())
+    reducer = GradBucketReducer(model)
+    decay = [p for n, p in model.named_parameters() if "bias" not in n]
+    no_decay = [p for n, p in model.named_parameters() if "bias" in n]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 1e-5}, {"params": no_decay, "weight_decay": 0.0}],
+                            lr=1e-4, fused=True)
+    pool = [synth_batch(B, L, 1234 + 1000 * rank + i, dev) for i in range(2)]
+
+    def step(i):
+        s1, s2 = pool[i % len(pool)]
+        mix = s1 + s2
+        spec, phase = dtt_amd.stft_mag_phase(mix, n_fft, hop)
+        sources = []
+        for s in (s1, s2):
+            sp, ph = dtt_amd.stft_mag_phase(s, n_fft, hop)
+            sources.append({"audio": s, "spectrogram": sp, "phase": ph})
+        batch = {"audio": mix, "spectrogram": spec, "phase": phase, "sources": sources, "audio_length": L}
+        reducer.zero_grad()
+        batch.update(model(**batch))
+        batch.update(criterion(**batch))
+        batch["loss"].backward()
+        reducer.finish()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 2.0, foreach=True)
+        opt.step()
+        return batch["loss"]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        loss = step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(loss.detach())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        roofline = dominant_kernel_roofline(B, args.precision, dev)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, n_fft, hop, L)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * cfg["seconds"] / (elapsed / args.steps)
+        step_tflops = 3 * cfg["fwd_gflop_per_item"] * B * world / (elapsed / args.steps) / 1e3
+        line = {
+            "metric": "separated audio-sec/sec (fwd+bwd, 16 kHz)", "value": round(value, 2), "unit": "audio-s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: DTTNet audio-only 15M training step (STFT+fwd+PIT-L1+bwd"
+                                   f"+clip+AdamW), B={B}/GPU x {cfg['seconds']:.0f} s, n_fft 1024 hop 256",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4),
+                       "model_tflops_per_s": round(step_tflops, 2),
+                       "mfma_frac_whole_step": round(step_tflops / (PEAK_BF16_TFLOPS * world), 4)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def dominant_kernel_roofline(B, precision, dev):
+    """Time the dominant kernel (the implicit-GEMM 3x3 conv at the full-resolution U-Net level,
+    32 -> 32 channels on [B,513,126]) with events on the stream it is launched on."""
+    from dtt_amd import ops
+    dt = torch.bfloat16 if precision == "bf16" else torch.float32
+    Fq, T, Cc = 513, 126, 32
+    x = torch.randn(B, Fq, T, Cc, device=dev).to(dt)
+    w = (torch.randn(Cc, Cc, 3, 3, device=dev) / 17.0)
+    bias = torch.zeros(Cc, device=dev)
+    wp = ops._pack_fwd(w, "s1", dt)
+    y = torch.empty_like(x)
+    _, _, gf, _, _ = ops._conv_geoms("s1", B, Fq, T, Cc, Cc)
+    for _ in range(3):
+        ops.conv_gemm(x, wp, bias, y, gf)
+    n = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        ops.conv_gemm(x, wp, bias, y, gf)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / n / 1e3
+    flops = 2.0 * B * Fq * T * Cc * 9 * Cc
+    achieved = flops / sec / 1e12
+    return {"kernel": "gemm_kernel (implicit-GEMM conv3x3 32->32 @ [B,513,126], 14 fwd + 14 dgrad launches/step)",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(sec * 1e6, 1), "flops_per_launch": flops}
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,101 @@ typedef struct DttGemm {
 } DttGemm;
 int dtt_gemm(const DttGemm* p, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * InstanceNorm2d(affine=False, eps) + exact GELU on channels-last tensors
+ * (block_tfc_tdf.py:15-16, block_sampling.py:10-11,26-27), incl. the decoder
+ * crop (decoder.py:46-52): statistics over the full (Fy,Ty) plane, output /
+ * incoming gradient on the cropped (Fz,Tz) plane.
+ *   partial: [B][ceil(P/chunk)][C][2] scratch, stats/sums: [B][C][2] fp32.
+ * ------------------------------------------------------------------------- */
+int dtt_in_stats(const void* y, float* partial, float* stats, int B, int P, int C, int chunk, float eps,
+                 int dtype, void* stream);
+int dtt_in_gelu_fwd(const void* y, const float* stats, void* z, int B, int Fy, int Ty, int Fz, int Tz, int C,
+                    int dtype, void* stream);
+int dtt_in_gelu_bwd(const void* y, const void* dz, const float* stats, float* partial, float* sums, void* dy,
+                    int B, int Fy, int Ty, int Fz, int Tz, int C, int chunk, int dtype, void* stream);
+
+/* GroupNorm over (gs channels x L steps) per sequence, fused with the (F,T)
+ * re-ordering of IDPModule (latent.py:47-54,82-85,100).  Slab o reads rows
+ * x + (o/NI)*OS + (o%NI)*IS + l*RS and writes [o][l][C] contiguously; xperm
+ * (optional) receives the un-normalised copy in the same order (residual).
+ * gn_bwd adds dres (same order) and scatters dx back; pgb: [nslab][C][2]. */
+int dtt_gn_fwd(const void* x, const float* gamma, const float* beta, void* xn, void* xperm, float* stats,
+               int nslab, int NI, int L, int C, int Cp, int gs, int64_t OS, int64_t IS, int64_t RS, float eps,
+               int dtype, void* stream);
+int dtt_gn_bwd(const void* x, const void* dxn, const void* dres, const float* gamma, const float* stats,
+               void* dx, float* pgb, int nslab, int NI, int L, int C, int Cp, int gs, int64_t OS, int64_t IS,
+               int64_t RS, int dtype, void* stream);
+
+/* Deterministic column sums (bias gradients): out[nchunks][W]. */
+int dtt_colsum(const void* in, float* out, int64_t R, int W, int64_t ld, int nchunks, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Persistent bidirectional LSTM recurrence, forward and backward through time
+ * (nn.LSTM(C', 2C', bidirectional), latent.py:87-92; gate order i,f,g,o).
+ * Rows: (outer*L + step)*heads + head.  xg [rows][2][4H] = x W_ih^T + b_ih + b_hh
+ * (from dtt_gemm); wp / wpt = W_hh in MFMA fragment order (see dtt_amd/ops.py);
+ * y [rows][2H]; gates [rows][2][4H]; cst [rows][2][H] fp32; dG [rows][2][4H].
+ * ------------------------------------------------------------------------- */
+int dtt_lstm_fwd(const void* xg, const void* wp, void* y, void* gates, float* cst, int N, int L, int heads, int H,
+                 int dtype, void* stream);
+int dtt_lstm_bwd(const void* dy, const void* gates, const float* cst, const void* wpt, void* dG, int N, int L,
+                 int heads, int H, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * STFT / iSTFT glue (base_dataset.py:154-167; model_dttnet.py:77-85), the 1x1
+ * input conv (encoder.py:26-27) and the fused out conv + mask + torch.polar
+ * (decoder.py:29; model_dttnet.py:47-78) with its backward (incl. polar's
+ * sgn() autograd rule).
+ * ------------------------------------------------------------------------- */
+int dtt_reflect_pad(const float* x, float* xp, int B, int L, int pad, void* stream);
+int dtt_stft_post(const float* reim, float* mag, float* phase, int B, int F, int T, int ld, int imoff,
+                  void* stream);
+int dtt_init_conv_fwd(const float* spec, const float* phase, const float* w, const float* bias, void* out,
+                      int64_t P, int C, int dtype, void* stream);
+int dtt_init_conv_bwd(const float* spec, const float* phase, const void* dout, float* partial, int64_t P, int C,
+                      int nchunks, int dtype, void* stream);
+int dtt_mask_fwd(const void* x, const float* w, const float* bias, const float* mspec, const float* mphase,
+                 float* pspec, float* pphase, void* Z, int B, int F, int T, int C, int S, int ldz, int imoff,
+                 int dtype, void* stream);
+int dtt_mask_bwd(const float* w, const float* mspec, const float* mphase, const float* pspec, const float* pphase,
+                 const float* dspec, const float* dphase, const float* dZ, void* dx, void* dmask, int B, int F,
+                 int T, int C, int S, int ldz, int imoff, int dtype, void* stream);
+int dtt_ola_fwd(const float* frames, float* out, int SB, int T, int n_fft, int hop, int length, void* stream);
+int dtt_ola_bwd(const float* dout, void* gpad, int SB, int T, int n_fft, int hop, int length, int dtype,
+                void* stream);
+
+/* ---------------------------------------------------------------------------
+ * PIT L1 loss (dttnet_loss.py:28-34, pit_loss_wrapper.py:41-71,
+ * dttnet_loss_wrapper.py:41-62) and SI-SNR (si_snr.py:26-34).
+ * pred: [S][B][n]; src: host array of S device pointers to [B][n] planes.
+ * ------------------------------------------------------------------------- */
+int dtt_l1_pairs(const float* pred, const float* const* src, float* partial, int S, int B, int64_t n,
+                 int nchunks, void* stream);
+int dtt_pit_select(const float* p_spec, const float* p_phase, const float* p_audio, int nc_sp, int nc_au,
+                   int64_t FT, int64_t L, int S, int B, int fixed_order, float* item_loss, int64_t* permuts,
+                   float* loss, void* stream);
+int dtt_l1_bwd(const float* pred, const float* const* src, const int64_t* permuts, const float* gloss, float scale,
+               float* dpred, int S, int B, int64_t n, void* stream);
+int dtt_sisnr(const float* est, const float* const* src, float* partial, float* alpha, float* out, int E, int S,
+              int B, int64_t L, int nchunks, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Elementwise: op 0 add / 1 mul (decoder.py:43 skip multiply); FiLM apply
+ * (block_fusion.py:30-37; gbc [B][T][2C] = gamma_c|beta_c, gbf [B][T][2F]);
+ * frequency-mean tokens and broadcast concat of the cross-attention fusion
+ * (cross_attention_positional.py:55,77-78).
+ * ------------------------------------------------------------------------- */
+int dtt_binary(int op, const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+int dtt_film_fwd(const void* x, const float* gbc, const float* gbf, void* y, int B, int F, int T, int C, int dtype,
+                 void* stream);
+int dtt_film_bwd(const void* x, const void* dy, const float* gbc, const float* gbf, void* dx, float* dgbc,
+                 float* dgbf, int B, int F, int T, int C, int dtype, void* stream);
+int dtt_fmean(const void* x, float* tok, int B, int F, int T, int C, int dtype, void* stream);
+int dtt_bcat_fwd(const void* x, const float* enh, void* out, int B, int F, int T, int C, int dtype, void* stream);
+int dtt_bcat_bwd(const void* dout, const float* dtok, void* dx, float* denh, int B, int F, int T, int C, int dtype,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

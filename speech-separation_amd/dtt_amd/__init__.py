@@ -2,7 +2,7 @@
 
 Host side of libdtt_hip.so; mirrors the reference's model / loss / metric
 classes (see ../src for the reference's own import paths)."""
-from .model import DTTNetModel  # noqa: F401
+from .model import DTTNetModel, DTTNetVisionModel, DTTNetPlusModel  # noqa: F401
 from .loss import DTTNetLoss, PITLossWrapper, DTTNetLossWrapper  # noqa: F401
 from .metrics import (SiSnr, SiSnrI, SiSnrPITTraining, SiSnrPITInference, SiSnrIPITTraining,  # noqa: F401
                       SiSnrIPITInference)

@@ -1,0 +1,112 @@
+"""Audio-visual fusion blocks on channels-last activations.
+
+Big-tensor work (frequency-mean tokens, FiLM apply, broadcast + concat, 1x1
+projection) runs in the HIP kernels; the token-level network (<= 50 tokens per
+item, 0.08-0.26 GFLOP/sample) is plain fp32 library GEMMs
+(rocBLAS through torch) plus elementwise ops on [B, <=50, C] tensors.
+
+Reference: src/model/VideoAudioFusions/{cross_attention_positional,
+temporal_alignment}.py, src/model/DTTNetPlus/blocks/block_fusion.py.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+
+def _build_sinusoids(length, dim, device):
+    """cross_attention_positional.py:6-12."""
+    pos = torch.arange(length, device=device, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, dim, 2, device=device, dtype=torch.float32) * (-math.log(10000.0) / dim))
+    pe = torch.zeros(length, dim, device=device)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+class CrossAttentionPositional(nn.Module):
+    """cross_attention_positional.py:15-80; input/outputs channels-last:
+    audio [B,F,T,C], video [B,C_v,E_v,T_v] (as the video encoder emits it) -> [B,F,T,2C]."""
+
+    def __init__(self, audio_channels, video_channels, n_heads=2):
+        super().__init__()
+        self.audio_channels, self.video_channels, self.n_heads = audio_channels, video_channels, n_heads
+        self.video_proj = nn.Sequential(nn.Linear(video_channels, audio_channels), nn.GELU())
+        self.q_audio = nn.Linear(audio_channels, audio_channels)
+        self.k_video = nn.Linear(audio_channels, audio_channels)
+        self.v_video = nn.Linear(audio_channels, audio_channels)
+        self.inp_layernorm = nn.LayerNorm(audio_channels)
+        self.attn_layernorm = nn.LayerNorm(audio_channels)
+        self.cross_attn = nn.MultiheadAttention(audio_channels, n_heads, dropout=0.0, batch_first=True)
+        self.cross_ffn = nn.Sequential(nn.Linear(audio_channels, 4 * audio_channels), nn.GELU(),
+                                       nn.Linear(4 * audio_channels, audio_channels))
+        self.audio_gate = nn.Sequential(nn.Linear(audio_channels, audio_channels), nn.Sigmoid())
+
+    def _tokens(self, a, video):
+        """Token-level network in fp32 (autocast disabled: tiny, keep it exact)."""
+        B, T, Cc = a.shape
+        _, Cv, Ev, Tv = video.shape
+        v = video.float().permute(0, 3, 1, 2).reshape(B, Tv, Cv * Ev)
+        v = F.gelu(F.linear(v, self.video_proj[0].weight, self.video_proj[0].bias))
+        a = a + _build_sinusoids(T, Cc, a.device).unsqueeze(0)
+        v = v + _build_sinusoids(Tv, Cc, a.device).unsqueeze(0)
+        ln = self.inp_layernorm
+        q = self.q_audio(F.layer_norm(a, (Cc,), ln.weight, ln.bias, ln.eps))
+        vn = F.layer_norm(v, (Cc,), ln.weight, ln.bias, ln.eps)
+        k, vv = self.k_video(vn), self.v_video(vn)
+        ca = self.cross_attn
+        H, dh = self.n_heads, Cc // self.n_heads
+        qp = F.linear(q, ca.in_proj_weight[:Cc], ca.in_proj_bias[:Cc]).view(B, T, H, dh).transpose(1, 2)
+        kp = F.linear(k, ca.in_proj_weight[Cc:2 * Cc], ca.in_proj_bias[Cc:2 * Cc]).view(B, Tv, H, dh).transpose(1, 2)
+        vp = F.linear(vv, ca.in_proj_weight[2 * Cc:], ca.in_proj_bias[2 * Cc:]).view(B, Tv, H, dh).transpose(1, 2)
+        att = torch.softmax(qp @ kp.transpose(-1, -2) / math.sqrt(dh), dim=-1)
+        o = (att @ vp).transpose(1, 2).reshape(B, T, Cc)
+        o = F.linear(o, ca.out_proj.weight, ca.out_proj.bias)
+        al = self.attn_layernorm
+        a = F.layer_norm(a + o, (Cc,), al.weight, al.bias, al.eps)
+        a = a + self.cross_ffn(a)
+        return a * self.audio_gate(a)
+
+    def forward(self, audio_features, video_features):
+        tok = ops.FreqMeanTokens.apply(audio_features)                 # [B,T,C] fp32
+        with torch.autocast("cuda", enabled=False):
+            enh = self._tokens(tok, video_features)
+        return ops.BroadcastConcat.apply(audio_features, enh)
+
+
+class TemporalAligner(nn.Module):
+    """temporal_alignment.py:6-25.  The video projection is constant over F, so the
+    bilinear resize (align_corners=False) reduces to linear interpolation over time."""
+
+    def __init__(self, audio_channels, video_channels):
+        super().__init__()
+        self.audio_projection = nn.Conv2d(audio_channels, audio_channels, 1)
+        self.video_projection = nn.Conv2d(video_channels, audio_channels, 1)
+
+    def forward(self, audio_features, video_features):
+        B, Fq, T, Cc = audio_features.shape
+        _, Cv, Ev, Tv = video_features.shape
+        with torch.autocast("cuda", enabled=False):
+            v = video_features.float().reshape(B, Cv * Ev, Tv)
+            w = self.video_projection.weight.reshape(Cc, Cv * Ev)
+            vp = torch.einsum("oc,bct->bot", w, v) + self.video_projection.bias[None, :, None]
+            if Tv != T:
+                vp = F.interpolate(vp, size=T, mode="linear", align_corners=False)
+            vp = vp.transpose(1, 2).contiguous()                      # [B,T,C]
+        a = ops.Conv1x1.apply(audio_features, self.audio_projection.weight, self.audio_projection.bias)
+        return ops.BroadcastConcat.apply(a, vp)
+
+
+def film_apply(block, x, video):
+    """FusionBlock.forward (block_fusion.py:16-37): x [B,F,T,C] channels-last, video [B,T_v,D]."""
+    T = x.shape[2]
+    with torch.autocast("cuda", enabled=False):
+        v = F.interpolate(video.float().transpose(-1, -2), size=T, mode="linear").transpose(-1, -2)   # [B,T,D]
+        gbc = torch.cat([block.w_gamma_channels(v), block.w_beta_channels(v)], dim=-1)              # [B,T,2C]
+        gbf = torch.cat([block.w_gamma_freq(v), block.w_beta_freq(v)], dim=-1)                      # [B,T,2F]
+    return ops.Film.apply(x, gbc, gbf)

@@ -282,3 +282,96 @@ class DTTNetModel(_SeparatorBase):
         x = self.latent(x)
         x = self.decoder(x, skips)
         return self.postprocess(x, spectrogram, phase, audio_length)
+
+
+class DTTNetVisionModel(_SeparatorBase):
+    """src/model/DTTNet/model_dttnet_vision.py:12-123 (audio-visual, fusion ahead of a
+    2x-wide latent, 1x1 channel compression after it)."""
+
+    def __init__(self, g=32, n_sources=2, n_layers=3, n_idp_layers=3, n_fft=512, hop_length=128, n_heads=2,
+                 video_channels=512, fusion_method="temporal_alignment", use_checkpoints=False, precision="auto",
+                 video_checkpoint_path=None):
+        super().__init__()
+        from .fusion import CrossAttentionPositional, TemporalAligner
+        from .video import VideoEncoder
+        self.n_sources, self.n_fft, self.hop_length, self.precision = n_sources, n_fft, hop_length, precision
+        fc_dim = n_fft // 2 + 1
+        self.audio_dim = g * 2 ** n_layers
+        self.fusion_method = fusion_method
+        self.video_encoder = VideoEncoder(video_checkpoint_path)
+        if fusion_method == "temporal_alignment":
+            self.fusion = TemporalAligner(self.audio_dim, 2 * video_channels)
+        elif fusion_method == "cross_attention_positional":
+            self.fusion = CrossAttentionPositional(self.audio_dim, 2 * video_channels, n_heads)
+        else:
+            raise ValueError(f"{self.fusion_method} audio-video fusion method is not supported yet")
+        self.encoder = Encoder(fc_dim, 2, g, n_layers, use_checkpoints)
+        self.decoder = Decoder(fc_dim, g, n_sources, n_layers, use_checkpoints)
+        self.latent = LatentModule((fc_dim + 2 ** n_layers) // 2 ** n_layers, n_heads, g * 2 ** n_layers * 2,
+                                   n_idp_layers)
+        self.channel_compression = nn.Sequential(nn.Conv2d(self.audio_dim * 2, self.audio_dim, 1),
+                                                 nn.InstanceNorm2d(self.audio_dim), nn.GELU())
+
+    def encode_video(self, video):
+        if self.compute_dtype() == torch.bfloat16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return self.video_encoder(video)
+        return self.video_encoder(video)
+
+    def forward(self, spectrogram, video, phase, audio_length, video_features=None, **batch):
+        self._check(spectrogram)
+        x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
+        if video_features is None:                      # (tests may feed encoder outputs directly)
+            video_features = self.encode_video(video)
+        x = self.fusion(x, video_features)
+        _Tap.put("fusion", x)
+        x = self.latent(x)
+        cc = self.channel_compression[0]
+        x = ops.Conv1x1NormGelu.apply(x, cc.weight, cc.bias)
+        _Tap.put("channel_compression", x)
+        x = self.decoder(x, skips)
+        return self.postprocess(x, spectrogram, phase, audio_length)
+
+
+class PassThroughVideoEmbedding(nn.Module):
+    """Stand-in for DTTNetPlus' frozen third-party lip-reading front end
+    (src/model/lipreading, 1.4k LoC, checkpoint not shipped: .MISSING_LARGE_BLOBS:1).
+    Holds the trainable ``post_processor`` of VideoEncoderModule
+    (DTTNetPlus/modules/video_encoder.py:34) and applies it to precomputed 2x1024-d
+    lip features; raw video is not supported in this round."""
+
+    def __init__(self, video_embed_dim):
+        super().__init__()
+        self.post_processor = nn.Linear(1024 * 2, video_embed_dim)
+
+    def forward(self, feats):
+        if feats.dim() != 3 or feats.shape[-1] != 2048:
+            raise DttError("DTTNetPlusModel expects precomputed lip features [B, T_v, 2048] "
+                           "(the ShuffleNetV2 front end is not part of this build)")
+        return self.post_processor(feats.float())
+
+
+class DTTNetPlusModel(_SeparatorBase):
+    """src/model/DTTNetPlus/model_dttnet.py:10-77: FiLM fusion between the latent TFC-TDF and the IDPs."""
+
+    def __init__(self, g=32, n_sources=2, n_layers=3, n_idp_layers=3, n_fft=1024, hop_length=128, n_heads=2,
+                 video_embed_dim=256, use_checkpoints=False, video_enc_weights_path=None, precision="auto",
+                 *args, **kwargs):
+        super().__init__()
+        self.n_sources, self.n_fft, self.hop_length, self.precision = n_sources, n_fft, hop_length, precision
+        fc_dim = n_fft // 2 + 1
+        self.encoder = Encoder(fc_dim, 2, g, n_layers, use_checkpoints)
+        self.video_encoder = PassThroughVideoEmbedding(video_embed_dim)
+        self.decoder = Decoder(fc_dim, g, n_sources, n_layers, use_checkpoints)
+        self.latent = LatentModule((fc_dim + 2 ** n_layers) // 2 ** n_layers, n_heads, g * 2 ** n_layers,
+                                   n_idp_layers, video_embed_dim=video_embed_dim)
+
+    def forward(self, spectrogram, phase, audio_length, video, video_encoded=None, **batch):
+        self._check(spectrogram)
+        x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
+        if video_encoded is None:
+            with torch.autocast("cuda", enabled=False):
+                video_encoded = self.video_encoder(video)
+        x = self.latent(x, video_encoded)
+        x = self.decoder(x, skips)
+        return self.postprocess(x, spectrogram, phase, audio_length)

@@ -628,3 +628,149 @@ def si_snr_matrix(est, sources, eps=1e-5):
     check(lib().dtt_sisnr(ptr(est), _ptr_array(sources), ptr(part), ptr(alpha), ptr(out), E, S, B, C.c_int64(L), nch,
                           C.c_float(eps), stream_ptr()), "dtt_sisnr")
     return out
+
+
+# --------------------------------------------------------------------------- #
+# 1x1 conv (+ InstanceNorm + GELU), FiLM, token mean / broadcast concat
+# --------------------------------------------------------------------------- #
+def _linear_fwd(x2d, w, b, out2d, res=None):
+    """out[r][n] = x[r][:] . w[n][:] + b[n] (+ res); w is [N][K] in x's dtype."""
+    R, K = x2d.shape
+    N = w.shape[0]
+    kw = dict(A=x2d, B=w, C=out2d, M=R, N=N, K=K, a_ms=K, a_ks=1, b_ks=1, b_ns=K, c_ms=N, c_ns=1, dtype=_dt(x2d))
+    if b is not None:
+        kw.update(bias=b, bias_mode=1)
+    if res is not None:
+        kw.update(R=res, r_ms=N, r_ns=1)
+    gemm_raw(**kw)
+
+
+def _linear_bwd(x2d, w, dy2d, need_dx=True):
+    R, K = x2d.shape
+    N = w.shape[0]
+    d = _dt(x2d)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x2d)
+        gemm_raw(A=dy2d, B=w, C=dx, M=R, N=K, K=N, a_ms=N, a_ks=1, b_ks=K, b_ns=1, c_ms=K, c_ns=1, dtype=d)
+    dw = torch.zeros(N, K, dtype=F32, device=x2d.device)
+    gemm_raw(A=dy2d, B=x2d, C=dw, M=N, N=K, K=R, splitk=max(1, min(256, R // 1024)), a_ms=1, a_ks=N, b_ks=K,
+             b_ns=1, c_ms=K, c_ns=1, dtype=d, atomic=1, out_f32=1)
+    return dx, dw
+
+
+class Conv1x1(torch.autograd.Function):
+    """1x1 conv on channels-last (temporal_alignment.py:9, audio_projection)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        Co, Ci = w.shape[0], w.shape[1]
+        wp = w.reshape(Co, Ci).to(x.dtype).contiguous()
+        y = _empty(x.shape[:-1] + (Co,), x.dtype, x.device)
+        _linear_fwd(x.reshape(-1, Ci), wp, b, y.view(-1, Co))
+        ctx.save_for_backward(x, wp)
+        ctx.wshape = w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp = ctx.saved_tensors
+        dy = dy.contiguous()
+        Co, Ci = wp.shape
+        dx, dw = _linear_bwd(x.reshape(-1, Ci), wp, dy.view(-1, Co), ctx.needs_input_grad[0])
+        db = colsum(dy, dy.numel() // Co, Co)
+        return (dx.view_as(x) if dx is not None else None), dw.view(ctx.wshape), db
+
+
+class Conv1x1NormGelu(torch.autograd.Function):
+    """channel_compression: 1x1 conv -> InstanceNorm2d -> GELU (model_dttnet_vision.py:73-77)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, Fq, T, Ci = x.shape
+        Co = w.shape[0]
+        wp = w.reshape(Co, Ci).to(x.dtype).contiguous()
+        y = _empty((B, Fq, T, Co), x.dtype, x.device)
+        _linear_fwd(x.view(-1, Ci), wp, b, y.view(-1, Co))
+        stats = in_stats(y)
+        z = in_gelu_fwd(y, stats, Fq, T)
+        ctx.save_for_backward(x, wp, y, stats)
+        ctx.wshape = w.shape
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, wp, y, stats = ctx.saved_tensors
+        Co, Ci = wp.shape
+        dy = in_gelu_bwd(y, dz.contiguous(), stats)
+        dx, dw = _linear_bwd(x.view(-1, Ci), wp, dy.view(-1, Co), ctx.needs_input_grad[0])
+        db = torch.zeros(Co, dtype=F32, device=x.device)       # bias ahead of InstanceNorm: exactly zero
+        return (dx.view_as(x) if dx is not None else None), dw.view(ctx.wshape), db
+
+
+class Film(torch.autograd.Function):
+    """(1 + gamma_c + gamma_f) * x + beta_c + beta_f  (block_fusion.py:30-37).
+    gbc [B,T,2C] = (gamma_c | beta_c), gbf [B,T,2F] = (gamma_f | beta_f), fp32."""
+
+    @staticmethod
+    def forward(ctx, x, gbc, gbf):
+        B, Fq, T, Cc = x.shape
+        gbc, gbf = gbc.contiguous().float(), gbf.contiguous().float()
+        y = torch.empty_like(x)
+        check(lib().dtt_film_fwd(ptr(x), ptr(gbc), ptr(gbf), ptr(y), B, Fq, T, Cc, _dt(x), stream_ptr()), "dtt_film_fwd")
+        ctx.save_for_backward(x, gbc, gbf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gbc, gbf = ctx.saved_tensors
+        B, Fq, T, Cc = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgbc, dgbf = torch.empty_like(gbc), torch.empty_like(gbf)
+        check(lib().dtt_film_bwd(ptr(x), ptr(dy), ptr(gbc), ptr(gbf), ptr(dx), ptr(dgbc), ptr(dgbf), B, Fq, T, Cc,
+                                 _dt(x), stream_ptr()), "dtt_film_bwd")
+        return dx, dgbc, dgbf
+
+
+class FreqMeanTokens(torch.autograd.Function):
+    """tokens[b,t,c] = mean_f x[b,f,t,c] (cross_attention_positional.py:55) -> fp32.
+    Its backward is folded into BroadcastConcat (the only consumer of x besides this)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, Fq, T, Cc = x.shape
+        tok = _empty((B, T, Cc), F32, x.device)
+        check(lib().dtt_fmean(ptr(x), ptr(tok), B, Fq, T, Cc, _dt(x), stream_ptr()), "dtt_fmean")
+        ctx.shape = x.shape
+        ctx.dt = x.dtype
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        B, Fq, T, Cc = ctx.shape
+        return (dtok / Fq).to(ctx.dt).unsqueeze(1).expand(B, Fq, T, Cc).contiguous()
+
+
+class BroadcastConcat(torch.autograd.Function):
+    """cat([x, enh[b,t,c] expanded over F], channel) (cross_attention_positional.py:77-78,
+    temporal_alignment.py:17-24)."""
+
+    @staticmethod
+    def forward(ctx, x, enh):
+        B, Fq, T, Cc = x.shape
+        enh = enh.contiguous().float()
+        out = _empty((B, Fq, T, 2 * Cc), x.dtype, x.device)
+        check(lib().dtt_bcat_fwd(ptr(x), ptr(enh), ptr(out), B, Fq, T, Cc, _dt(x), stream_ptr()), "dtt_bcat_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Fq, T, C2 = dout.shape
+        Cc = C2 // 2
+        dout = dout.contiguous()
+        dx = _empty((B, Fq, T, Cc), dout.dtype, dout.device)
+        denh = _empty((B, T, Cc), F32, dout.device)
+        check(lib().dtt_bcat_bwd(ptr(dout), None, ptr(dx), ptr(denh), B, Fq, T, Cc, _dt(dout), stream_ptr()),
+              "dtt_bcat_bwd")
+        return dx, denh

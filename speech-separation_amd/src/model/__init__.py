@@ -1,3 +1,3 @@
-from dtt_amd.model import DTTNetModel  # noqa: F401
+from dtt_amd.model import DTTNetModel, DTTNetVisionModel, DTTNetPlusModel  # noqa: F401
 
-__all__ = ["DTTNetModel"]
+__all__ = ["DTTNetModel", "DTTNetVisionModel", "DTTNetPlusModel"]

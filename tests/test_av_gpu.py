@@ -1,0 +1,108 @@
+"""GPU parity of the audio-visual pieces (FiLM, cross-attention, temporal aligner,
+ResNet-18 lip encoder, tiny AV model) against fixtures generated from the reference."""
+import pytest
+import torch
+
+from oracle.fill import fill_state_dict, synth_video
+from conftest import load_golden, load_manifest
+from helpers import make_batch, rel_err, grad_close, to_dev
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _nhwc(x, dt=torch.float32):
+    return x.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV)
+
+
+def _nchw(x):
+    return x.detach().permute(0, 3, 1, 2).float().cpu()
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_film_block(dt, tol):
+    from dtt_amd.model import FusionBlock, LatentModule
+    fx = load_golden("film")
+    fb = FusionBlock(16, 5, 24).to(DEV)
+    fb.load_state_dict(fill_state_dict(load_manifest("film"), 4))
+    a = _nhwc(fx["a"], dt).requires_grad_(True)
+    v = fx["v"].to(DEV).requires_grad_(True)
+    y = fb(a, v)
+    assert rel_err(_nchw(y), fx["y"]) < tol
+    y.backward(_nhwc(fx["gy"], dt))
+    g = 5e-5 if dt == torch.float32 else 3e-2
+    assert rel_err(_nchw(a.grad), fx["ga"]) < g and rel_err(v.grad, fx["gv"]) < g
+    for k, p in fb.named_parameters():
+        assert grad_close(p.grad, fx["grad." + k], g, atol=2e-6 if dt == torch.float32 else 2e-3), k
+    if dt == torch.float32:
+        lat = LatentModule(5, 2, 32, 1, video_embed_dim=24).to(DEV)
+        lat.load_state_dict(fill_state_dict(load_manifest("film_latent"), 5))
+        out = lat(_nhwc(fx["lat_in"]), fx["v"].to(DEV))
+        assert rel_err(_nchw(out), fx["lat_out"]) < 2e-5
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_cross_attention_and_temporal_aligner(dt, tol):
+    from dtt_amd.fusion import CrossAttentionPositional, TemporalAligner
+    fx = load_golden("xattn")
+    ca = CrossAttentionPositional(32, 48, 2).to(DEV)
+    ca.load_state_dict(fill_state_dict(load_manifest("xattn"), 6))
+    a = _nhwc(fx["a"], dt).requires_grad_(True)
+    v = fx["v"].to(DEV).requires_grad_(True)
+    y = ca(a, v)
+    assert rel_err(_nchw(y), fx["y"]) < tol
+    y.backward(_nhwc(fx["gy"], dt))
+    g = 5e-5 if dt == torch.float32 else 3e-2
+    assert rel_err(_nchw(a.grad), fx["ga"]) < g and rel_err(v.grad, fx["gv"]) < g
+    for k, p in ca.named_parameters():
+        assert grad_close(p.grad, fx["grad." + k], 2e-4 if dt == torch.float32 else 3e-2,
+                          atol=2e-6 if dt == torch.float32 else 2e-3), k
+    ta = TemporalAligner(32, 48).to(DEV)
+    ta.load_state_dict(fill_state_dict(load_manifest("temporal_aligner"), 7))
+    assert rel_err(_nchw(ta(_nhwc(fx["a"], dt), fx["v"].to(DEV))), fx["ta_y"]) < tol
+
+
+def test_resnet18_video_encoder():
+    from dtt_amd.video import VideoEncoder
+    fx = load_golden("resnet18")
+    enc = VideoEncoder().to(DEV)
+    enc.load_state_dict(fill_state_dict(load_manifest("resnet18"), 8))
+    vid = synth_video(1, 3, seed=9).to(DEV)
+    enc.eval()
+    assert rel_err(enc(vid), fx["y_eval"]) < 1e-3
+    enc.train()
+    assert rel_err(enc(vid), fx["y_train"]) < 1e-3
+
+
+def test_tiny_xattn_model_fp32():
+    import dtt_amd
+    from dtt_amd.model import _Tap
+    fx = load_golden("tiny_xattn")
+    man = load_manifest("tiny_xattn")
+    model = dtt_amd.DTTNetVisionModel(g=8, n_sources=2, n_layers=3, n_idp_layers=1, n_fft=64, hop_length=16,
+                                      n_heads=2, video_channels=24, fusion_method="cross_attention_positional",
+                                      precision="fp32").to(DEV)
+    missing, unexpected = model.load_state_dict(fill_state_dict(man, 10), strict=False)
+    assert not unexpected and all(k.startswith("video_encoder.") for k in missing)
+    b = to_dev(make_batch(2, 800, 64, 16, seed=12), DEV)
+    _Tap.store = {}
+    try:
+        out = model(video=None, video_features=fx["in.video_features"].to(DEV), **b)
+    finally:
+        taps, _Tap.store = _Tap.store, None
+    assert rel_err(taps["fusion"], fx["tap.fusion"]) < 2e-5
+    assert rel_err(taps["channel_compression"], fx["tap.channel_compression"]) < 1e-4
+    assert rel_err(taps["decoder.out_conv"], fx["tap.decoder.out_conv"]) < 2e-4
+    b.update(out)
+    res = dtt_amd.PITLossWrapper()(**b)
+    assert torch.equal(res["batch_permuts"].cpu(), fx["batch_permuts"])
+    assert rel_err(res["loss"], fx["loss"]) < 1e-5
+    res["loss"].backward()
+    params = dict(model.named_parameters())
+    for k in [k[5:] for k in fx if k.startswith("grad.")]:
+        assert rel_err(params[k].grad, fx["grad." + k]) < 3e-3, k
+    b.update(res)
+    v = dtt_amd.SiSnrIPITInference()(**b)
+    assert abs(float(v) - float(fx["metric.SiSnrIPITInference"])) < 0.05
+    with pytest.raises(ValueError):
+        dtt_amd.DTTNetVisionModel(fusion_method="nope")

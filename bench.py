@@ -28,7 +28,13 @@ PEAK_HBM_GBS = 8000.0
 WORKLOADS = {
     # BASELINE.json configs[1]: DTTNet audio-only 15M training step, B=64 x 2 s bf16
     "audio15m": dict(model="audio", g=32, n_idp=4, batch=64, seconds=2.0, fwd_gflop_per_item=96.6),
+    # configs[3]: DTTNet AV cross-attention 60M, B=16 x 2 s bf16 + 25 fps 88x88 lip ROI (ResNet-18 = stock MIOpen)
+    "xattn60m": dict(model="xattn", g=32, n_idp=4, batch=16, seconds=2.0, fwd_gflop_per_item=271.3),
+    # configs[2]: DTTNet AV FiLM 25M, B=64 x 2 s (lip features precomputed: frozen 3rd-party front end not built)
+    "film25m": dict(model="film", g=32, n_idp=4, batch=64, seconds=2.0, fwd_gflop_per_item=96.6),
 }
+NAMES = {"audio": "DTTNet audio-only 15M", "xattn": "DTTNet AV cross-attention 60M (ResNet-18 lip encoder in the step)",
+         "film": "DTTNet AV FiLM (lip features precomputed)"}
 
 
 def synth_batch(B, L, seed, dev):
@@ -119,8 +125,24 @@ def main():
     L = int(cfg["seconds"] * SR)
 
     torch.manual_seed(1)                       # train.yaml:56; same weights on every rank
-    model = dtt_amd.DTTNetModel(g=cfg["g"], n_sources=2, n_layers=3, n_idp_layers=cfg["n_idp"], n_fft=n_fft,
-                                hop_length=hop, n_heads=2, use_checkpoints=True, precision=args.precision).to(dev)
+    common = dict(g=cfg["g"], n_sources=2, n_layers=3, n_idp_layers=cfg["n_idp"], n_fft=n_fft, hop_length=hop,
+                  n_heads=2, use_checkpoints=True, precision=args.precision)
+    if cfg["model"] == "audio":
+        model = dtt_amd.DTTNetModel(**common).to(dev)
+    elif cfg["model"] == "xattn":
+        model = dtt_amd.DTTNetVisionModel(video_channels=512, fusion_method="cross_attention_positional",
+                                          **common).to(dev)
+    else:
+        model = dtt_amd.DTTNetPlusModel(video_embed_dim=512, **common).to(dev)
+    Tv = int(cfg["seconds"] * 25)
+    gv = torch.Generator(device=dev)
+    gv.manual_seed(99 + rank)
+    if cfg["model"] == "xattn":
+        video = (torch.rand(B, 2, Tv, 88, 88, generator=gv, device=dev) - 0.421) / 0.165
+    elif cfg["model"] == "film":
+        video = torch.randn(B, Tv, 2048, generator=gv, device=dev)
+    else:
+        video = None
     criterion = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())
     reducer = GradBucketReducer(model)
     decay = [p for n, p in model.named_parameters() if "bias" not in n]
@@ -138,6 +160,8 @@ def main():
             sp, ph = dtt_amd.stft_mag_phase(s, n_fft, hop)
             sources.append({"audio": s, "spectrogram": sp, "phase": ph})
         batch = {"audio": mix, "spectrogram": spec, "phase": phase, "sources": sources, "audio_length": L}
+        if video is not None:
+            batch["video"] = video
         reducer.zero_grad()
         batch.update(model(**batch))
         batch.update(criterion(**batch))
@@ -170,7 +194,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         roofline = dominant_kernel_roofline(B, args.precision, dev)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and cfg["model"] == "audio":
         cpu = cpu_baseline(cfg, n_fft, hop, L)
 
     if rank == 0:
@@ -182,7 +206,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: DTTNet audio-only 15M training step (STFT+fwd+PIT-L1+bwd"
+            "config": {"workload": f"{args.workload}: {NAMES[cfg['model']]} training step (STFT+fwd+PIT-L1+bwd"
                                    f"+clip+AdamW), B={B}/GPU x {cfg['seconds']:.0f} s, n_fft 1024 hop 256",
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4),
                        "model_tflops_per_s": round(step_tflops, 2),

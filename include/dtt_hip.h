@@ -62,6 +62,17 @@ typedef struct DttGemm {
 } DttGemm;
 int dtt_gemm(const DttGemm* p, void* stream);
 
+/* Dedicated 3x3 stride-1 'same' conv on channels-last (block_tfc_tdf.py:12-32): LDS input
+ * patches shared by the nine taps; wp = [Co][9][Ci]; optional fused residual and fused
+ * InstanceNorm statistics (partial scratch [B][ceil(F/16)][ceil(T/16)][Co][2] -> stats
+ * [B][Co][2] = {mean, rstd}).  The same kernel computes the data gradient (flipped weights).
+ * dtt_conv3x3_wgrad: dw[Co][9][Ci] fp32 += sum_px dy[px][co] x[px+tap][ci] (bf16 operands,
+ * transposing LDS reads; caller zeroes dw). */
+int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, void* y, const void* res, float* partial,
+                   float* stats, int B, int F, int T, int Ci, int Co, float eps, int dtype, void* stream);
+int dtt_conv3x3_wgrad(const void* dy, const void* x, float* dw, int B, int F, int T, int Ci, int Co, int dtype,
+                      void* stream);
+
 /* ---------------------------------------------------------------------------
  * InstanceNorm2d(affine=False, eps) + exact GELU on channels-last tensors
  * (block_tfc_tdf.py:15-16, block_sampling.py:10-11,26-27), incl. the decoder

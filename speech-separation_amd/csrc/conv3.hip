@@ -1,0 +1,331 @@
+// Dedicated 3x3 stride-1 "same" convolution kernels on channels-last tensors
+// (the 49 TFC convs + 49 data-gradient convs + 49 weight-gradient reductions of a
+// training step: block_tfc_tdf.py:12-32).  Input patches (16x16 pixels + halo) are
+// staged once in LDS and re-used by all nine taps; the forward kernel also emits the
+// per-tile InstanceNorm statistics from its fp32 accumulators.
+//
+//   conv3x3_s1_kernel : y[b,f,t,co] = bias[co] + sum_{tap,ci} x[b,f+kh-1,t+kw-1,ci] w[co][tap][ci] (+ res)
+//   conv3x3_wgrad_kernel (bf16): dw[co][tap][ci] += sum_px dy[px][co] * x[px+tap][ci]
+//       pixels are the MFMA K dimension; operands are read from the natural
+//       [pixel][channel] LDS image with the transposing ds_read_b64_tr_b16.
+#include "common.h"
+#include "../../include/dtt_hip.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16, PH = TH + 2, PW = TW + 2, KC = 32;
+
+struct Conv3P {
+    const void* x; const void* wp; const float* bias; void* y; const void* res; float* partial;
+    int B, F, T, Ci, Co, tiles_f, tiles_t;
+};
+
+// waves: 4 along M (each 4 tile rows = 64 px, TM = 2), all of BN = 32*TN output channels.
+template <typename T, int TN>
+__global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
+    constexpr int EPT = MM<T>::EPT, LDC = KC + MM<T>::PAD, BN = 32 * TN, CPR = KC / EPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* patch = reinterpret_cast<T*>(smem);                  // [PH*PW][LDC]
+    T* wl = patch + PH * PW * LDC;                          // [9*BN][LDC]
+    __shared__ float red[4][2 * BN];
+    __shared__ float tmean[BN];
+
+    const int ntile_n = p.Co / BN;
+    int bid = blockIdx.x;
+    const int nt = bid % ntile_n; bid /= ntile_n;
+    const int tt = bid % p.tiles_t, tf = bid / p.tiles_t;
+    const int b = blockIdx.y;
+    const int f0 = tf * TH, t0 = tt * TW, co0 = nt * BN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const T* x = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.F * p.T * p.Ci;
+    const T* wp = reinterpret_cast<const T*>(p.wp);
+
+    f32x16_t acc[2][TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.f;
+
+    const int nchunks = (p.Ci + KC - 1) / KC;
+    for (int c = 0; c < nchunks; ++c) {
+        const int ci0 = c * KC;
+        if (c) __syncthreads();
+        // ---- stage the input patch (zero outside the image / beyond Ci)
+        for (int idx = tid; idx < PH * PW * CPR; idx += 256) {
+            int pp = idx / CPR, ch = idx % CPR;
+            int pf = pp / PW, pt = pp - pf * PW;
+            int f = f0 - 1 + pf, t = t0 - 1 + pt, ci = ci0 + ch * EPT;
+            Vec16<T> v = zero16<T>();
+            if (f >= 0 && f < p.F && t >= 0 && t < p.T && ci < p.Ci) v = ld16<T>(x + ((int64_t)f * p.T + t) * p.Ci + ci);
+            st16<T>(patch + pp * LDC + ch * EPT, v);
+        }
+        // ---- stage the weights of this channel chunk: wl[tap][col][ci]
+        for (int idx = tid; idx < 9 * BN * CPR; idx += 256) {
+            int row = idx / CPR, ch = idx % CPR;
+            int tap = row / BN, col = row - tap * BN, ci = ci0 + ch * EPT;
+            Vec16<T> v = zero16<T>();
+            if (ci < p.Ci) v = ld16<T>(wp + ((int64_t)(co0 + col) * 9 + tap) * p.Ci + ci);
+            st16<T>(wl + row * LDC + ch * EPT, v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int kofs = s * 16 + lh * 8;
+                typename MM<T>::Frag af[2], bf[TN];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    int prow = wave * 4 + a * 2 + (lr >> 4) + kh, pcol = (lr & 15) + kw;
+                    af[a] = MM<T>::ldfrag(patch + (prow * PW + pcol) * LDC + kofs);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = MM<T>::ldfrag(wl + (tap * BN + j * 32 + lr) * LDC + kofs);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) MM<T>::mma(af[a], bf[j], acc[a][j]);
+            }
+        }
+    }
+
+    // ---- epilogue: lane owns channel co0 + j*32 + lr, 16 pixels per (a) tile
+    T* y = reinterpret_cast<T*>(p.y) + (int64_t)b * p.F * p.T * p.Co;
+    const T* res = p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)b * p.F * p.T * p.Co : nullptr;
+    float bsv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bsv[j] = p.bias ? p.bias[co0 + j * 32 + lr] : 0.f;
+    float s1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) s1[j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int f = f0 + wave * 4 + a * 2 + (i >> 4), t = t0 + (i & 15);
+            const bool ok = f < p.F && t < p.T;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v = acc[a][j][r] + bsv[j];
+                acc[a][j][r] = v;
+                if (ok) {
+                    s1[j] += v;
+                    const int64_t o = ((int64_t)f * p.T + t) * p.Co + co0 + j * 32 + lr;
+                    stf(y + o, res ? v + ldf(res + o) : v);
+                }
+            }
+        }
+    if (!p.partial) return;
+    // ---- per-tile InstanceNorm statistics {mean, M2} per channel
+    const int nf = min(TH, p.F - f0), ntv = min(TW, p.T - t0);
+    const float inv_cnt = 1.f / (float)(nf * ntv);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float s = s1[j] + __shfl_xor(s1[j], 32, 64);
+        if (lh == 0) red[wave][j * 32 + lr] = s;
+    }
+    __syncthreads();
+    if (tid < BN) tmean[tid] = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) * inv_cnt;
+    __syncthreads();
+    float s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) s2[j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int f = f0 + wave * 4 + a * 2 + (i >> 4), t = t0 + (i & 15);
+            if (f < p.F && t < p.T) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { float d = acc[a][j][r] - tmean[j * 32 + lr]; s2[j] += d * d; }
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float s = s2[j] + __shfl_xor(s2[j], 32, 64);
+        if (lh == 0) red[wave][BN + j * 32 + lr] = s;
+    }
+    __syncthreads();
+    if (tid < BN) {
+        float* d = p.partial + ((((int64_t)b * p.tiles_f + tf) * p.tiles_t + tt) * p.Co + co0 + tid) * 2;
+        d[0] = tmean[tid];
+        d[1] = red[0][BN + tid] + red[1][BN + tid] + red[2][BN + tid] + red[3][BN + tid];
+    }
+}
+
+// merge the per-tile partials (Chan) -> stats[b][c] = {mean, rstd}
+__global__ void conv_stats_finalize(const float* __restrict__ partial, float* __restrict__ stats, int F, int T, int C,
+                                    int tiles_f, int tiles_t, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int tf = 0; tf < tiles_f; ++tf)
+        for (int tt = 0; tt < tiles_t; ++tt) {
+            const float* s = partial + ((((int64_t)b * tiles_f + tf) * tiles_t + tt) * C + c) * 2;
+            float nb = (float)(min(TH, F - tf * TH) * min(TW, T - tt * TW));
+            float d = s[0] - mean, nn = n + nb;
+            mean += d * nb / nn;
+            m2 += s[1] + d * d * n * nb / nn;
+            n = nn;
+        }
+    stats[((int64_t)b * C + c) * 2] = mean;
+    stats[((int64_t)b * C + c) * 2 + 1] = rsqrtf(m2 / n + eps);
+}
+
+// ------------------------------------------------------------------------------------
+// weight gradient, bf16.  WG = 4 waves; CT = channels per side held in LDS (32 or 64).
+//   CT == 32: the 4 waves split the tile's pixels (4 rows each), every wave holds 9 taps.
+//   CT == 64: waves 2x2 over (co half, ci half), every wave sees all 256 pixels.
+// Each WG walks a range of pixel tiles accumulating in registers, then adds atomically.
+// ------------------------------------------------------------------------------------
+struct Wg3P {
+    const void* dy; const void* x; float* dw;
+    int B, F, T, Ci, Co, tiles_f, tiles_t, tiles_per_wg;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ s16x8_t tr_frag(const bf16* r0, const bf16* r1) {
+    // two transposing reads of 4 k-rows each -> 8 consecutive k for this lane's column
+    s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)r0);
+    s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)r1);
+    s16x8_t v;
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    return v;
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(Wg3P p) {
+    constexpr int LD = CT + 8;                               // bf16 elements; rows stay 16-byte aligned
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* dyl = reinterpret_cast<bf16*>(smem);               // [TH*TW][LD]
+    bf16* xl = dyl + TH * TW * LD;                           // [PH*PW][LD]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CT;
+    const int wm = (CT == 64) ? (wave >> 1) : 0, wn = (CT == 64) ? (wave & 1) : 0;
+    const bf16* dy = reinterpret_cast<const bf16*>(p.dy);
+    const bf16* x = reinterpret_cast<const bf16*>(p.x);
+    // lane roles for the transposing read
+    const int g = lane >> 4, h = lane >> 5, q = (lane & 15) >> 2, pq = lane & 3;
+    const int colofs = 16 * (g & 1) + 4 * pq;
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int ntiles = p.B * p.tiles_f * p.tiles_t;
+    const int tile0 = blockIdx.x * p.tiles_per_wg, tile1 = min(ntiles, tile0 + p.tiles_per_wg);
+    for (int tile = tile0; tile < tile1; ++tile) {
+        int r = tile;
+        const int tt = r % p.tiles_t; r /= p.tiles_t;
+        const int tf = r % p.tiles_f, b = r / p.tiles_f;
+        const int f0 = tf * TH, t0 = tt * TW;
+        if (tile != tile0) __syncthreads();
+        constexpr int CPR = CT / 8;
+        for (int idx = tid; idx < TH * TW * CPR; idx += 256) {
+            int pp = idx / CPR, ch = idx % CPR;
+            int f = f0 + (pp >> 4), t = t0 + (pp & 15);
+            Vec16<bf16> v = zero16<bf16>();
+            if (f < p.F && t < p.T) v = ld16<bf16>(dy + (((int64_t)b * p.F + f) * p.T + t) * p.Co + co0 + ch * 8);
+            st16<bf16>(dyl + pp * LD + ch * 8, v);
+        }
+        for (int idx = tid; idx < PH * PW * CPR; idx += 256) {
+            int pp = idx / CPR, ch = idx % CPR;
+            int pf = pp / PW, pt = pp - pf * PW;
+            int f = f0 - 1 + pf, t = t0 - 1 + pt;
+            Vec16<bf16> v = zero16<bf16>();
+            if (f >= 0 && f < p.F && t >= 0 && t < p.T) v = ld16<bf16>(x + (((int64_t)b * p.F + f) * p.T + t) * p.Ci + ci0 + ch * 8);
+            st16<bf16>(xl + pp * LD + ch * 8, v);
+        }
+        __syncthreads();
+        const int kr0 = (CT == 64) ? 0 : wave * 4, kr1 = (CT == 64) ? TH : wave * 4 + 4;
+        for (int kr = kr0; kr < kr1; ++kr) {
+            // one k-step = the 16 pixels of tile row kr; this lane supplies k = 8h + 4j + q
+            const int kc0 = 8 * h + q, kc1 = kc0 + 4;
+            const bf16* a0 = dyl + (kr * 16 + kc0) * LD + wm * 32 + colofs;
+            const bf16* a1 = dyl + (kr * 16 + kc1) * LD + wm * 32 + colofs;
+            s16x8_t af = tr_frag(a0, a1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+                const bf16* b0 = xl + ((kr + kh) * PW + kc0 + kw) * LD + wn * 32 + colofs;
+                const bf16* b1 = xl + ((kr + kh) * PW + kc1 + kw) * LD + wn * 32 + colofs;
+                s16x8_t bfv = tr_frag(b0, b1);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af),
+                                                                   __builtin_bit_cast(bf16x8_t, bfv), acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    // ---- atomic accumulate: rows = co, cols = ci
+    const int lr = lane & 31;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int co = co0 + wm * 32 + i, ci = ci0 + wn * 32 + lr;
+            if (co < p.Co && ci < p.Ci) atomicAdd(p.dw + ((int64_t)co * 9 + tap) * p.Ci + ci, acc[tap][r]);
+        }
+}
+
+}  // namespace
+
+#define ST reinterpret_cast<hipStream_t>(stream)
+
+// y = conv3x3_same(x, wp [Co][9][Ci]) + bias (+ res); if partial != NULL also the InstanceNorm
+// statistics: partial scratch [B][tiles_f][tiles_t][Co][2], stats [B][Co][2] = {mean, rstd}.
+extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, void* y, const void* res,
+                              float* partial, float* stats, int B, int F, int T, int Ci, int Co, float eps, int dtype,
+                              void* stream) {
+    const int ept = dtype ? 8 : 4;
+    DTT_CHECK(B > 0 && F > 0 && T > 0 && Ci % ept == 0 && Co % 32 == 0, "dtt_conv3x3_s1: unsupported Ci=%d Co=%d", Ci, Co);
+    Conv3P p{x, wp, bias, y, res, partial, B, F, T, Ci, Co, (F + TH - 1) / TH, (T + TW - 1) / TW};
+    const int tn = (Co % 64 == 0) ? 2 : 1, bn = 32 * tn;
+    const int ldc = KC + (dtype ? 8 : 4), es = dtype ? 2 : 4;
+    size_t sm = (size_t)(PH * PW + 9 * bn) * ldc * es;
+    dim3 grid(p.tiles_f * p.tiles_t * (Co / bn), B);
+#define LAUNCH(TT, TN_) do { auto k = conv3x3_s1_kernel<TT, TN_>; \
+        if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        hipLaunchKernelGGL(k, grid, dim3(256), sm, ST, p); } while (0)
+    if (dtype) { if (tn == 2) LAUNCH(bf16, 2); else LAUNCH(bf16, 1); }
+    else { if (tn == 2) LAUNCH(float, 2); else LAUNCH(float, 1); }
+#undef LAUNCH
+    if (partial)
+        hipLaunchKernelGGL(conv_stats_finalize, dim3((Co + 127) / 128, B), dim3(128), 0, ST, partial, stats, F, T, Co,
+                           p.tiles_f, p.tiles_t, eps);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+// dw [Co][9][Ci] fp32 (zeroed by the caller) += sum over pixels; bf16 only.
+extern "C" int dtt_conv3x3_wgrad(const void* dy, const void* x, float* dw, int B, int F, int T, int Ci, int Co,
+                                 int dtype, void* stream) {
+    DTT_CHECK(dtype == 1, "dtt_conv3x3_wgrad: bf16 only (fp32 goes through dtt_gemm)");
+    DTT_CHECK(B > 0 && F > 0 && T > 0 && Ci % 32 == 0 && Co % 32 == 0, "dtt_conv3x3_wgrad: unsupported Ci=%d Co=%d", Ci, Co);
+    Wg3P p{dy, x, dw, B, F, T, Ci, Co, (F + TH - 1) / TH, (T + TW - 1) / TW, 1};
+    const int ct = (Ci % 64 == 0 && Co % 64 == 0) ? 64 : 32;
+    const int ntiles = B * p.tiles_f * p.tiles_t;
+    const int combos = (Co / ct) * (Ci / ct);
+    int nsplit = max(1, min(ntiles, (1024 + combos - 1) / combos));
+    p.tiles_per_wg = (ntiles + nsplit - 1) / nsplit;
+    nsplit = (ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    size_t sm = (size_t)(TH * TW + PH * PW) * (ct + 8) * 2;
+    dim3 grid(nsplit, Co / ct, Ci / ct);
+    if (ct == 64) {
+        auto k = conv3x3_wgrad_kernel<64>;
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(k, grid, dim3(256), sm, ST, p);
+    } else {
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, grid, dim3(256), sm, ST, p);
+    }
+    DTT_LAUNCH_CHECK();
+    return 0;
+}

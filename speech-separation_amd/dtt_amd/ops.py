@@ -108,6 +108,25 @@ def in_gelu_bwd(y, dz, stats):
     return dy
 
 
+def _fast3(x, Co):
+    """The dedicated 3x3 stride-1 kernels need 32-multiples of output channels."""
+    return Co % 32 == 0 and x.shape[3] % (8 if x.dtype == torch.bfloat16 else 4) == 0
+
+
+def conv3x3_s1(x, wp, bias, res=None, want_stats=False, eps=1e-5):
+    """x [B,F,T,Ci], wp [Co][9*Ci] -> y [B,F,T,Co] (+ InstanceNorm stats [B,Co,2])."""
+    B, Fq, T, Ci = x.shape
+    Co = wp.shape[0]
+    y = _empty((B, Fq, T, Co), x.dtype, x.device)
+    part = stats = None
+    if want_stats:
+        part = _empty((B, (Fq + 15) // 16, (T + 15) // 16, Co, 2), F32, x.device)
+        stats = _empty((B, Co, 2), F32, x.device)
+    check(lib().dtt_conv3x3_s1(ptr(x), ptr(wp), ptr(bias), ptr(y), ptr(res), ptr(part), ptr(stats), B, Fq, T, Ci, Co,
+                               C.c_float(eps), _dt(x), stream_ptr()), "dtt_conv3x3_s1")
+    return y, stats
+
+
 def binary(op, a, b):
     out = torch.empty_like(a)
     check(lib().dtt_binary(op, ptr(a), ptr(b), ptr(out), C.c_int64(a.numel()), _dt(a), stream_ptr()), "dtt_binary")
@@ -159,6 +178,16 @@ def _conv_backward(kind, x, w, dy, need_dx):
     B, Fi, Ti, Ci = x.shape
     Co = dy.shape[3]
     _, _, _, gd, gw = _conv_geoms(kind, B, Fi, Ti, Ci, Co)
+    if kind == "s1" and _fast3(dy, Ci) and _fast3(x, Co):
+        if x.dtype == torch.bfloat16:
+            dwp = torch.zeros(Co, 9, Ci, dtype=F32, device=x.device)
+            check(lib().dtt_conv3x3_wgrad(ptr(dy), ptr(x), ptr(dwp), B, Fi, Ti, Ci, Co, 1, stream_ptr()),
+                  "dtt_conv3x3_wgrad")
+        else:
+            dwp = conv_wgrad(dy, x, gw, Co, Ci)
+        dw = dwp.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
+        dx = conv3x3_s1(dy, _pack_dgrad(w, kind, x.dtype), None)[0] if need_dx else None
+        return dx, dw
     if kind == "up":
         dwp = conv_wgrad(x, dy, gw, Ci, Co)                      # [Ci][9][Co]
         dw = dwp.view(Ci, 3, 3, Co).permute(0, 3, 1, 2)
@@ -181,9 +210,12 @@ class ConvNormGelu(torch.autograd.Function):
         B, Fi, Ti, Ci = x.shape
         Co = w.shape[1] if kind == "up" else w.shape[0]
         Fo, To, gf, _, _ = _conv_geoms(kind, B, Fi, Ti, Ci, Co)
-        y = _empty((B, Fo, To, Co), x.dtype, x.device)
-        conv_gemm(x, _pack_fwd(w, kind, x.dtype), b, y, gf)
-        stats = in_stats(y)
+        if kind == "s1" and _fast3(x, Co):
+            y, stats = conv3x3_s1(x, _pack_fwd(w, kind, x.dtype), b, want_stats=True)
+        else:
+            y = _empty((B, Fo, To, Co), x.dtype, x.device)
+            conv_gemm(x, _pack_fwd(w, kind, x.dtype), b, y, gf)
+            stats = in_stats(y)
         Fz, Tz = (Fo, To) if crop is None else crop
         z = in_gelu_fwd(y, stats, Fz, Tz)
         ctx.save_for_backward(x, w, y, stats)
@@ -208,8 +240,11 @@ class ConvAdd(torch.autograd.Function):
         B, Fi, Ti, Ci = x.shape
         Co = w.shape[0]
         _, _, gf, _, _ = _conv_geoms("s1", B, Fi, Ti, Ci, Co)
-        y = _empty((B, Fi, Ti, Co), x.dtype, x.device)
-        conv_gemm(x, _pack_fwd(w, "s1", x.dtype), b, y, gf, res=h)
+        if _fast3(x, Co):
+            y = conv3x3_s1(x, _pack_fwd(w, "s1", x.dtype), b, res=h)[0]
+        else:
+            y = _empty((B, Fi, Ti, Co), x.dtype, x.device)
+            conv_gemm(x, _pack_fwd(w, "s1", x.dtype), b, y, gf, res=h)
         ctx.save_for_backward(x, w)
         return y
 

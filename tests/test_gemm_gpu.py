@@ -160,3 +160,38 @@ def test_gemm_row_shift(dt):
                  c_ms=H, c_ns=1, dtype=dtype_code(dt), atomic=1, out_f32=1, b_mode=2,
                  sh_shift=shift_steps * heads, sh_heads=heads, sh_L=L, sh_edge=edge)
         assert rel_err(c, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Ci,Co,Fq,T", [(32, 32, 33, 20), (64, 64, 17, 13), (32, 96, 16, 16), (128, 64, 9, 35)])
+def test_conv3x3_dedicated_kernels(dt, Ci, Co, Fq, T):
+    """dtt_conv3x3_s1 (+ fused residual and InstanceNorm statistics) and dtt_conv3x3_wgrad."""
+    from dtt_amd import ops
+    g = torch.Generator().manual_seed(Ci * 3 + Co + Fq)
+    dev = "cuda"
+    Bn = 3
+    x = _mk((Bn, Ci, Fq, T), dt, g)
+    w = (_mk((Co, Ci, 3, 3), dt, g).float() / (3 * Ci ** 0.5)).to(dt)
+    bias = torch.randn(Co, generator=g)
+    res = _mk((Bn, Co, Fq, T), dt, g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    wp = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous().to(dev)
+    xd = _nhwc(x).to(dev)
+    y, stats = ops.conv3x3_s1(xd, wp, bias.to(dev), want_stats=True)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL[dt]
+    mean = ref.mean(dim=(2, 3))
+    rstd = 1.0 / torch.sqrt(ref.var(dim=(2, 3), unbiased=False) + 1e-5)
+    assert rel_err(stats[..., 0], mean) < (1e-5 if dt == torch.float32 else 2e-3)
+    assert rel_err(stats[..., 1], rstd) < (1e-5 if dt == torch.float32 else 2e-3)
+    y2, _ = ops.conv3x3_s1(xd, wp, bias.to(dev), res=_nhwc(res).to(dev))
+    assert rel_err(y2.permute(0, 3, 1, 2), ref + res.double()) < TOL[dt]
+    if dt == torch.bfloat16:
+        import ctypes as C
+        from dtt_amd._lib import lib, check, ptr, stream_ptr
+        dy = _mk((Bn, Co, Fq, T), dt, g)
+        xr = x.double()
+        wr = w.double().requires_grad_(True)
+        F.conv2d(xr, wr, None, padding=1).backward(dy.double())
+        dwp = torch.zeros(Co, 9, Ci, dtype=torch.float32, device=dev)
+        check(lib().dtt_conv3x3_wgrad(ptr(_nhwc(dy).to(dev)), ptr(xd), ptr(dwp), Bn, Fq, T, Ci, Co, 1, stream_ptr()), "wgrad")
+        assert rel_err(dwp, wr.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)) < TOL[dt]

@@ -23,14 +23,15 @@ struct LstmP {
     int N, L, heads, H;
 };
 
-// wave w owns hidden columns j in [(w*TJ)*32, (w*TJ+TJ)*32) for all four gates.
-template <typename T, int TM, int TJ>
+// NW = min(8, H/32) waves; the hidden columns are processed in NP = H/(32*NW) sequential passes,
+// wave w owning columns j = (q*NW + w)*32 .. +31 in pass q, all four gates of a column in one lane.
+template <typename T, int PF>
 __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = p.H, LDH = H + MM<T>::PAD;
-    constexpr int NB = 32 * TM;
+    constexpr int NB = 32;
     T* hbuf = reinterpret_cast<T*>(smem);                 // [2][NB][LDH]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
     const int dir = blockIdx.y, n0 = blockIdx.x * NB;
     const int KS = H / 16, G4 = 4 * H;
     const T* xg = reinterpret_cast<const T*>(p.xg);
@@ -38,81 +39,86 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmP p) {
     T* y = reinterpret_cast<T*>(p.y);
     T* gates = reinterpret_cast<T*>(p.gates);
 
-    // per-lane sequence rows of the C layout: r -> local row (r&3)+8(r>>2)+4*lh
-    float cst[TM][TJ][16];
+    // per-lane sequence rows of the C layout: r -> local row (r&3)+8(r>>2)+4*lh.
+    // rb = row of step 0 of that sequence (-1: beyond N); all offsets fit 32 bits (checked on the host)
+    int rb[16];
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TJ; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cst[a][b][r] = 0.f;
-
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        rb[r] = n < p.N ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
+    }
+    const int NP = H / (32 * nw);
     for (int s = 0; s < p.L; ++s) {
         const int t = dir ? p.L - 1 - s : s;
+        const int tprev = dir ? t + 1 : t - 1;
         const int cur = s & 1;
-        f32x16_t acc[TM][4][TJ];
-        // ---- init accumulators with the input projection
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const bool ok = n < p.N;
-                const int64_t row = ((int64_t)(n / p.heads) * p.L + t) * p.heads + (n % p.heads);
-                const T* src = xg + (row * 2 + dir) * G4;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int b = 0; b < TJ; ++b)
-                        acc[a][g][b][r] = ok ? ldf(src + g * H + (wave * TJ + b) * 32 + lr) : 0.f;
-            }
-        // ---- recurrent term h_{t-1} * W_hh^T
-        if (s > 0) {
-            const T* hb = hbuf + cur * NB * LDH;
-            for (int ks = 0; ks < KS; ++ks) {
-                typename MM<T>::Frag af[TM];
-#pragma unroll
-                for (int a = 0; a < TM; ++a) af[a] = MM<T>::ldfrag(hb + (a * 32 + lr) * LDH + ks * 16 + lh * 8);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int b = 0; b < TJ; ++b) {
-                        const int tile = g * (H / 32) + wave * TJ + b;
-                        typename MM<T>::Frag bf = MM<T>::ldfrag(wp + (((int64_t)tile * KS + ks) * 64 + lane) * 8);
-#pragma unroll
-                        for (int a = 0; a < TM; ++a) MM<T>::mma(af[a], bf, acc[a][g][b]);
-                    }
-            }
-        }
-        // ---- gates, state update, stores
+        const T* hb = hbuf + cur * NB * LDH;
         T* hn = hbuf + (cur ^ 1) * NB * LDH;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int q = 0; q < NP; ++q) {
+            const int jt = q * nw + wave;                 // 32-column tile of this pass
+            f32x16_t acc[4];
+            // ---- init accumulators with the input projection; previous cell state comes back from
+            // the global cst buffer (written by this same lane one step ago, L2-hot)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int nl = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int n = n0 + nl;
-                const bool ok = n < p.N;
-                const int64_t row = ((int64_t)(n / p.heads) * p.L + t) * p.heads + (n % p.heads);
+                const bool ok = rb[r] >= 0;
+                const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
+                const T* src = xg + (row * 2u + dir) * (uint32_t)G4 + jt * 32 + lr;
 #pragma unroll
-                for (int b = 0; b < TJ; ++b) {
-                    const int j = (wave * TJ + b) * 32 + lr;
-                    float ig = sigmoid_f(acc[a][0][b][r]), fg = sigmoid_f(acc[a][1][b][r]);
-                    float gg = tanh_f(acc[a][2][b][r]), og = sigmoid_f(acc[a][3][b][r]);
-                    float c = fg * cst[a][b][r] + ig * gg;
-                    cst[a][b][r] = c;
-                    float h = og * tanh_f(c);
-                    stf(hn + nl * LDH + j, h);
-                    if (ok) {
-                        stf(y + row * 2 * H + dir * H + j, h);
-                        if (gates) {
-                            T* gd = gates + (row * 2 + dir) * G4 + j;
-                            stf(gd, ig); stf(gd + H, fg); stf(gd + 2 * H, gg); stf(gd + 3 * H, og);
-                            p.cst[(row * 2 + dir) * H + j] = c;
+                for (int g = 0; g < 4; ++g) acc[g][r] = ok ? ldf(src + g * H) : 0.f;
+            }
+            // ---- recurrent term h_{t-1} * W_hh^T; W fragments are prefetched one k-step ahead
+            if (s > 0) {
+                typename MM<T>::Frag bq[PF + 1][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    bq[0][g] = MM<T>::ldfrag(wp + (((int64_t)(g * (H / 32) + jt) * KS) * 64 + lane) * 8);
+                for (int ks = 0; ks < KS; ks += 2) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int k = ks + u;
+                        if (PF) {
+                            if (k + 1 < KS) {
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+                                    bq[(u ^ 1) & PF][g] =
+                                        MM<T>::ldfrag(wp + (((int64_t)(g * (H / 32) + jt) * KS + k + 1) * 64 + lane) * 8);
+                            }
+                        } else if (k > 0) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                bq[0][g] = MM<T>::ldfrag(wp + (((int64_t)(g * (H / 32) + jt) * KS + k) * 64 + lane) * 8);
                         }
+                        typename MM<T>::Frag af = MM<T>::ldfrag(hb + lr * LDH + k * 16 + lh * 8);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) MM<T>::mma(af, bq[u & PF][g], acc[g]);
                     }
                 }
             }
+            // ---- gates, state update, stores
+            const int j = jt * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const bool ok = rb[r] >= 0;
+                const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
+                float ig = sigmoid_f(acc[0][r]), fg = sigmoid_f(acc[1][r]);
+                float gg = tanh_f(acc[2][r]), og = sigmoid_f(acc[3][r]);
+                const uint32_t rowp = (uint32_t)(ok && s > 0 ? rb[r] + tprev * p.heads : 0);
+                const float cprev = (ok && s > 0) ? p.cst[(rowp * 2u + dir) * (uint32_t)H + j] : 0.f;
+                float c = fg * cprev + ig * gg;
+                float h = og * tanh_f(c);
+                stf(hn + nl * LDH + j, h);
+                if (ok) {
+                    stf(y + (row * 2u + dir) * (uint32_t)H + j, h);
+                    p.cst[(row * 2u + dir) * (uint32_t)H + j] = c;
+                    if (gates) {
+                        T* gd = gates + (row * 2u + dir) * (uint32_t)G4 + j;
+                        stf(gd, ig); stf(gd + H, fg); stf(gd + 2 * H, gg); stf(gd + 3 * H, og);
+                    }
+                }
+            }
+        }
         __syncthreads();
     }
 }
@@ -126,13 +132,16 @@ struct LstmBwdP {
     int N, L, heads, H, kch;     // kch: gates staged in LDS per pass (4, 2 or 1)
 };
 
-template <typename T, int TM, int TJ>
+// STAGE_ALL: all four gate gradients of a step fit LDS at once and are written there straight from
+// registers; otherwise they are staged chunk by chunk from the (L2-hot) global dG this workgroup
+// has just written (workgroup-scope release/acquire around the barrier).
+template <typename T, int NP, bool STAGE_ALL>
 __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = p.H, kch = p.kch, LDG = kch * H + MM<T>::PAD;
-    constexpr int NB = 32 * TM;
+    constexpr int NB = 32, EPT = MM<T>::EPT;
     T* dgbuf = reinterpret_cast<T*>(smem);                // [NB][LDG]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
     const int dir = blockIdx.y, n0 = blockIdx.x * NB;
     const int G4 = 4 * H, KS = G4 / 16;
     const T* dy = reinterpret_cast<const T*>(p.dy);
@@ -140,86 +149,93 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
     const T* wpt = reinterpret_cast<const T*>(p.wpt) + (int64_t)dir * G4 * H;
     T* dG = reinterpret_cast<T*>(p.dG);
 
-    float dcs[TM][TJ][16];
-    f32x16_t dhr[TM][TJ];
+    int rb[16];
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        rb[r] = n < p.N ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
+    }
+    float dcs[NP][16];
+    f32x16_t dhr[NP];
 #pragma unroll
-        for (int b = 0; b < TJ; ++b)
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { dcs[a][b][r] = 0.f; dhr[a][b][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { dcs[q][r] = 0.f; dhr[q][r] = 0.f; }
 
     for (int s = p.L - 1; s >= 0; --s) {
         const int t = dir ? p.L - 1 - s : s;
         const int tprev = dir ? t + 1 : t - 1;          // forward-pass predecessor step
-        float dgv[TM][4][TJ][16];
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int q = 0; q < NP; ++q) {
+            const int j = (q * nw + wave) * 32 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int nl = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int n = n0 + nl;
-                const bool ok = n < p.N;
-                const int64_t rb = (int64_t)(n / p.heads) * p.L, hd = n % p.heads;
-                const int64_t row = (rb + t) * p.heads + hd, rowp = (rb + tprev) * p.heads + hd;
-#pragma unroll
-                for (int b = 0; b < TJ; ++b) {
-                    const int j = (wave * TJ + b) * 32 + lr;
-                    float di = 0.f, df = 0.f, dg = 0.f, dog_ = 0.f;
-                    if (ok) {
-                        const T* gs = gates + (row * 2 + dir) * G4 + j;
-                        float ig = ldf(gs), fg = ldf(gs + H), gg = ldf(gs + 2 * H), og = ldf(gs + 3 * H);
-                        float c = p.cst[(row * 2 + dir) * H + j];
-                        float cp = (s > 0) ? p.cst[(rowp * 2 + dir) * H + j] : 0.f;
-                        float dh = ldf(dy + row * 2 * H + dir * H + j) + dhr[a][b][r];
-                        float tc = tanh_f(c);
-                        dog_ = dh * tc * og * (1.f - og);
-                        float dc = dcs[a][b][r] + dh * og * (1.f - tc * tc);
-                        di = dc * gg * ig * (1.f - ig);
-                        df = dc * cp * fg * (1.f - fg);
-                        dg = dc * ig * (1.f - gg * gg);
-                        dcs[a][b][r] = dc * fg;
-                        T* gd = dG + (row * 2 + dir) * G4 + j;
-                        stf(gd, di); stf(gd + H, df); stf(gd + 2 * H, dg); stf(gd + 3 * H, dog_);
-                    }
-                    dgv[a][0][b][r] = di; dgv[a][1][b][r] = df; dgv[a][2][b][r] = dg; dgv[a][3][b][r] = dog_;
+                const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const bool ok = rb[r] >= 0;
+                const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
+                const uint32_t rowp = (uint32_t)(ok && s > 0 ? rb[r] + tprev * p.heads : 0);
+                float di = 0.f, df = 0.f, dg = 0.f, dog_ = 0.f;
+                if (ok) {
+                    const T* gs = gates + (row * 2u + dir) * (uint32_t)G4 + j;
+                    float ig = ldf(gs), fg = ldf(gs + H), gg = ldf(gs + 2 * H), og = ldf(gs + 3 * H);
+                    float c = p.cst[(row * 2u + dir) * (uint32_t)H + j];
+                    float cp = (s > 0) ? p.cst[(rowp * 2u + dir) * (uint32_t)H + j] : 0.f;
+                    float dh = ldf(dy + (row * 2u + dir) * (uint32_t)H + j) + dhr[q][r];
+                    float tc = tanh_f(c);
+                    dog_ = dh * tc * og * (1.f - og);
+                    float dc = dcs[q][r] + dh * og * (1.f - tc * tc);
+                    di = dc * gg * ig * (1.f - ig);
+                    df = dc * cp * fg * (1.f - fg);
+                    dg = dc * ig * (1.f - gg * gg);
+                    dcs[q][r] = dc * fg;
+                    T* gd = dG + (row * 2u + dir) * (uint32_t)G4 + j;
+                    stf(gd, di); stf(gd + H, df); stf(gd + 2 * H, dg); stf(gd + 3 * H, dog_);
+                }
+                if (STAGE_ALL) {
+                    T* ld = dgbuf + nl * LDG + j;
+                    stf(ld, di); stf(ld + H, df); stf(ld + 2 * H, dg); stf(ld + 3 * H, dog_);
                 }
             }
+        }
         if (s == 0) break;
-        // ---- dh_{t-1} = dG_t * W_hh, K = 4H staged through LDS kch gates at a time
+        // ---- dh_{t-1} = dG_t * W_hh, K = 4H
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int b = 0; b < TJ; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dhr[a][b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) dhr[q][r] = 0.f;
+        if (!STAGE_ALL) __threadfence_block();
         for (int g0 = 0; g0 < 4; g0 += kch) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < g0 || g >= g0 + kch) continue;
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TJ; ++b)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int nl = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            stf(dgbuf + nl * LDG + (g - g0) * H + (wave * TJ + b) * 32 + lr, dgv[a][g][b][r]);
-                        }
+            if (!STAGE_ALL) {
+                if (g0) __syncthreads();
+                else __syncthreads();
+                // stage dG[rows of this block][g0*H .. (g0+kch)*H) from global
+                const int cpr = kch * H / EPT;
+                for (int idx = threadIdx.x; idx < NB * cpr; idx += blockDim.x) {
+                    const int nl = idx / cpr, ch = idx - nl * cpr;
+                    const int n = n0 + nl;
+                    Vec16<T> v = zero16<T>();
+                    if (n < p.N) {
+                        const uint32_t row = (uint32_t)((n / p.heads) * p.L * p.heads + (n % p.heads) + t * p.heads);
+                        v = ld16<T>(dG + (row * 2u + dir) * (uint32_t)G4 + g0 * H + ch * EPT);
+                    }
+                    st16<T>(dgbuf + nl * LDG + ch * EPT, v);
+                }
             }
             __syncthreads();
-            const int ks0 = g0 * H / 16, ks1 = (g0 + kch) * H / 16;
-            for (int ks = ks0; ks < ks1; ++ks) {
-                typename MM<T>::Frag af[TM];
+            const int ks0 = g0 * H / 16, ks1 = (g0 + kch) * H / 16;       // even count: H % 32 == 0
 #pragma unroll
-                for (int a = 0; a < TM; ++a)
-                    af[a] = MM<T>::ldfrag(dgbuf + (a * 32 + lr) * LDG + (ks - ks0) * 16 + lh * 8);
+            for (int q = 0; q < NP; ++q) {
+                const int jt = q * nw + wave;
+                typename MM<T>::Frag bq[2];
+                bq[0] = MM<T>::ldfrag(wpt + (((int64_t)jt * KS + ks0) * 64 + lane) * 8);
+                for (int ks = ks0; ks < ks1; ks += 2) {
 #pragma unroll
-                for (int b = 0; b < TJ; ++b) {
-                    const int tile = wave * TJ + b;
-                    typename MM<T>::Frag bf = MM<T>::ldfrag(wpt + (((int64_t)tile * KS + ks) * 64 + lane) * 8);
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) MM<T>::mma(af[a], bf, dhr[a][b]);
+                    for (int u = 0; u < 2; ++u) {
+                        const int k = ks + u;
+                        if (k + 1 < ks1) bq[u ^ 1] = MM<T>::ldfrag(wpt + (((int64_t)jt * KS + k + 1) * 64 + lane) * 8);
+                        typename MM<T>::Frag af = MM<T>::ldfrag(dgbuf + lr * LDG + (k - ks0) * 16 + lh * 8);
+                        MM<T>::mma(af, bq[u], dhr[q]);
+                    }
                 }
             }
             __syncthreads();
@@ -227,61 +243,71 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
     }
 }
 
-template <typename T, int TM, int TJ>
-int launch_fwd(const LstmP& p, hipStream_t st) {
-    const int nw = p.H / (32 * TJ), NB = 32 * TM;
-    size_t sm = (size_t)2 * NB * (p.H + MM<T>::PAD) * sizeof(T);
-    auto k = lstm_fwd_kernel<T, TM, TJ>;
+template <typename T, int PF>
+int launch_fwd(const LstmP& p, int nw, hipStream_t st) {
+    size_t sm = (size_t)2 * 32 * (p.H + MM<T>::PAD) * sizeof(T);
+    DTT_CHECK(sm <= 160 * 1024, "dtt_lstm_fwd: H=%d does not fit LDS in this dtype", p.H);
+    auto k = lstm_fwd_kernel<T, PF>;
     if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(k, dim3((p.N + NB - 1) / NB, 2), dim3(nw * 64), sm, st, p);
+    hipLaunchKernelGGL(k, dim3((p.N + 31) / 32, 2), dim3(nw * 64), sm, st, p);
     DTT_LAUNCH_CHECK();
     return 0;
 }
 
-template <typename T, int TM, int TJ>
-int launch_bwd(LstmBwdP p, hipStream_t st) {
-    const int nw = p.H / (32 * TJ), NB = 32 * TM;
+template <typename T, int NP>
+int launch_bwd(LstmBwdP p, int nw, hipStream_t st) {
     int kch = 4;
-    while (kch > 1 && (size_t)NB * (kch * p.H + MM<T>::PAD) * sizeof(T) > 150 * 1024) kch >>= 1;
-    size_t sm = (size_t)NB * (kch * p.H + MM<T>::PAD) * sizeof(T);
+    while (kch > 1 && (size_t)32 * (kch * p.H + MM<T>::PAD) * sizeof(T) > 150 * 1024) kch >>= 1;
+    size_t sm = (size_t)32 * (kch * p.H + MM<T>::PAD) * sizeof(T);
     DTT_CHECK(sm <= 160 * 1024, "dtt_lstm_bwd: H=%d does not fit LDS", p.H);
     p.kch = kch;
-    auto k = lstm_bwd_kernel<T, TM, TJ>;
-    if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(k, dim3((p.N + NB - 1) / NB, 2), dim3(nw * 64), sm, st, p);
+    if (kch == 4) {
+        auto k = lstm_bwd_kernel<T, NP, true>;
+        if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(k, dim3((p.N + 31) / 32, 2), dim3(nw * 64), sm, st, p);
+    } else {
+        auto k = lstm_bwd_kernel<T, NP, false>;
+        if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(k, dim3((p.N + 31) / 32, 2), dim3(nw * 64), sm, st, p);
+    }
     DTT_LAUNCH_CHECK();
     return 0;
 }
 
-int pick_tj(int H) { return H > 256 ? 2 : 1; }
+int lstm_shape(int H, int& nw, int& np) {
+    nw = H / 32 < 8 ? H / 32 : 8;
+    np = H / (32 * nw);
+    return (H % 32 == 0 && H >= 32 && H % (32 * nw) == 0 && (np == 1 || np == 2 || np == 4)) ? 0 : -1;
+}
 
 }  // namespace
 
 extern "C" int dtt_lstm_fwd(const void* xg, const void* wp, void* y, void* gates, float* cst, int N, int L, int heads,
                             int H, int dtype, void* stream) {
-    DTT_CHECK(H % 32 == 0 && H >= 32 && H <= 512 && N > 0 && L > 0 && heads > 0 && N % heads == 0,
+    int nw, np;
+    DTT_CHECK(lstm_shape(H, nw, np) == 0 && N > 0 && L > 0 && heads > 0 && N % heads == 0,
               "dtt_lstm_fwd: unsupported shape H=%d N=%d L=%d", H, N, L);
+    DTT_CHECK((int64_t)N * L * 8 * H < (1LL << 31), "dtt_lstm_fwd: buffers exceed 32-bit element offsets");
     LstmP p{xg, wp, y, gates, cst, N, L, heads, H};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int tj = pick_tj(H);
-    DTT_CHECK(H % (32 * tj) == 0 && H / (32 * tj) <= 8, "dtt_lstm_fwd: H=%d", H);
-    const bool big = N >= 64 * 200 && (size_t)2 * 64 * (H + 8) * (dtype ? 2 : 4) <= 150 * 1024;
-    if (dtype) {
-        if (tj == 2) return launch_fwd<bf16, 1, 2>(p, st);
-        return big ? launch_fwd<bf16, 2, 1>(p, st) : launch_fwd<bf16, 1, 1>(p, st);
-    }
-    if (tj == 2) return launch_fwd<float, 1, 2>(p, st);
-    return big ? launch_fwd<float, 2, 1>(p, st) : launch_fwd<float, 1, 1>(p, st);
+    DTT_CHECK(cst != nullptr, "dtt_lstm_fwd: cst scratch is required (cell state round-trips through it)");
+    return dtype ? launch_fwd<bf16, 1>(p, nw, st) : launch_fwd<float, 1>(p, nw, st);
 }
 
 extern "C" int dtt_lstm_bwd(const void* dy, const void* gates, const float* cst, const void* wpt, void* dG, int N,
                             int L, int heads, int H, int dtype, void* stream) {
-    DTT_CHECK(H % 32 == 0 && H >= 32 && H <= 512 && N > 0 && L > 0 && heads > 0 && N % heads == 0,
+    int nw, np;
+    DTT_CHECK(lstm_shape(H, nw, np) == 0 && N > 0 && L > 0 && heads > 0 && N % heads == 0,
               "dtt_lstm_bwd: unsupported shape H=%d N=%d L=%d", H, N, L);
+    DTT_CHECK((int64_t)N * L * 8 * H < (1LL << 31), "dtt_lstm_bwd: buffers exceed 32-bit element offsets");
     LstmBwdP p{dy, gates, cst, wpt, dG, N, L, heads, H, 4};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int tj = pick_tj(H);
-    DTT_CHECK(H % (32 * tj) == 0 && H / (32 * tj) <= 8, "dtt_lstm_bwd: H=%d", H);
-    if (dtype) return tj == 2 ? launch_bwd<bf16, 1, 2>(p, st) : launch_bwd<bf16, 1, 1>(p, st);
-    return tj == 2 ? launch_bwd<float, 1, 2>(p, st) : launch_bwd<float, 1, 1>(p, st);
+    if (dtype) {
+        if (np == 1) return launch_bwd<bf16, 1>(p, nw, st);
+        if (np == 2) return launch_bwd<bf16, 2>(p, nw, st);
+        return launch_bwd<bf16, 4>(p, nw, st);
+    }
+    if (np == 1) return launch_bwd<float, 1>(p, nw, st);
+    if (np == 2) return launch_bwd<float, 2>(p, nw, st);
+    return launch_bwd<float, 4>(p, nw, st);
 }

@@ -366,7 +366,7 @@ class DualPathRNN(torch.autograd.Function):
         y = _empty((R, 2 * H), dt, dev)
         need = any(ctx.needs_input_grad)
         gates = _empty((R, 2, 4 * H), dt, dev) if need else None
-        cst = _empty((R, 2, H), F32, dev) if need else None
+        cst = _empty((R, 2, H), F32, dev)            # always: the cell state round-trips through it
         N = nslab * heads
         check(lib().dtt_lstm_fwd(ptr(xg), ptr(wp), ptr(y), ptr(gates), ptr(cst), N, L, heads, H, d, stream_ptr()),
               "dtt_lstm_fwd")

@@ -107,6 +107,21 @@ template <> struct MM<float> {
     }
 };
 
+// Transposing LDS read (gfx950 ds_read_b64_tr_b16): from a natural [k rows][columns] bf16 image,
+// lane l (group g = l>>4, q = (l&15)>>2, p = l&3) passes the address of row (kbase + 8*(l>>5) + q),
+// columns c0 + 16*(g&1) + 4p .. +3, and receives for column c0 + (l&31) the 8 consecutive k
+// 8*(l>>5) .. +7 -- exactly the 32x32x16 MFMA operand fragment.  r0/r1: row addresses for the
+// first / second group of 4 k.  Every lane of the wave must execute it.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ s16x8_t tr_frag(const bf16* r0, const bf16* r1) {
+    s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)r0);
+    s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)r1);
+    s16x8_t v;
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    return v;
+}
+
 // Host side error plumbing (api.cpp)
 extern "C" const char* dtt_last_error();
 void dtt_set_error(const char* fmt, ...);

@@ -188,18 +188,6 @@ struct Wg3P {
     int B, F, T, Ci, Co, tiles_f, tiles_t, tiles_per_wg;
 };
 
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-
-__device__ __forceinline__ s16x8_t tr_frag(const bf16* r0, const bf16* r1) {
-    // two transposing reads of 4 k-rows each -> 8 consecutive k for this lane's column
-    s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)r0);
-    s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)r1);
-    s16x8_t v;
-    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    return v;
-}
-
 template <int CT>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(Wg3P p) {
     constexpr int LD = CT + 8;                               // bf16 elements; rows stay 16-byte aligned

@@ -127,11 +127,13 @@ struct TileLoader {
                     st16<T>(lds + row * LDS_LD + ch * EPT, regs[it]);
                 } else {
                     int kl = idx / (ROWS / EPT), rc = idx % (ROWS / EPT);
+                    if constexpr (sizeof(T) == 2) {
+                        // bf16: keep the natural [k][rows] image; fragments come from transposing reads
+                        st16<T>(lds + kl * (ROWS + 8) + rc * EPT, regs[it]);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < EPT; ++e) {
-                        T* d = lds + (rc * EPT + e) * LDS_LD + kl;
-                        if constexpr (sizeof(T) == 2) d->x = (unsigned short)(((&regs[it].v.x)[e >> 1]) >> ((e & 1) * 16));
-                        else *reinterpret_cast<float*>(d) = regs[it].get(e);
+                        for (int e = 0; e < EPT; ++e)
+                            *reinterpret_cast<float*>(lds + (rc * EPT + e) * LDS_LD + kl) = regs[it].get(e);
                     }
                 }
             }
@@ -144,9 +146,14 @@ template <typename T, int WGM, int WGN, int WGK, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_kernel(const DttGemm p) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 32 * WGK;
     constexpr int LD = BK + MM<T>::PAD;
-    __shared__ __attribute__((aligned(16))) T lds[(BM + BN) * LD];
+    constexpr int ASZ = BM * LD > BK * (BM + 8) ? BM * LD : BK * (BM + 8);
+    constexpr int BSZ = BN * LD > BK * (BN + 8) ? BN * LD : BK * (BN + 8);
+    __shared__ __attribute__((aligned(16))) T lds[ASZ + BSZ];
     T* As = lds;
-    T* Bs = lds + BM * LD;
+    T* Bs = lds + ASZ;
+    // bf16 operands that are contiguous along rows (not k) sit in LDS as [k][rows] and are read transposed
+    const bool a_tr = sizeof(T) == 2 && !(p.a_ks == 1 || p.a_mode == 1) && p.a_ms == 1;
+    const bool b_tr = sizeof(T) == 2 && p.b_ks != 1 && p.b_ns == 1;
 
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tm_idx = blockIdx.x / tiles_n, tn_idx = blockIdx.x % tiles_n;
@@ -191,15 +198,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DttGemm p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int kofs = wk * 32 + s * 16 + lh * 8;
+            typename MM<T>::Frag af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const T* ap = As + ((wm * TM + i) * 32 + lr) * LD + kofs;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const T* bp = Bs + ((wn * TN + j) * 32 + lr) * LD + kofs;
-                    MM<T>::mma(MM<T>::ldfrag(ap), MM<T>::ldfrag(bp), acc[i][j]);
+                if constexpr (sizeof(T) == 2) {
+                    if (a_tr) {
+                        const bf16* r0 = reinterpret_cast<const bf16*>(As) + (kofs + ((lane & 15) >> 2)) * (BM + 8) +
+                                         (wm * TM + i) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                        af[i] = tr_frag(r0, r0 + 4 * (BM + 8));
+                        continue;
+                    }
                 }
+                af[i] = MM<T>::ldfrag(As + ((wm * TM + i) * 32 + lr) * LD + kofs);
             }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (sizeof(T) == 2) {
+                    if (b_tr) {
+                        const bf16* r0 = reinterpret_cast<const bf16*>(Bs) + (kofs + ((lane & 15) >> 2)) * (BN + 8) +
+                                         (wn * TN + j) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                        bf[j] = tr_frag(r0, r0 + 4 * (BN + 8));
+                        continue;
+                    }
+                }
+                bf[j] = MM<T>::ldfrag(Bs + ((wn * TN + j) * 32 + lr) * LD + kofs);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) MM<T>::mma(af[i], bf[j], acc[i][j]);
         }
         __syncthreads();
     }

@@ -52,6 +52,14 @@ template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
 template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& r) {
     *reinterpret_cast<decltype(r.v)*>(p) = r.v;
 }
+// Predicated 16-byte load WITHOUT a branch: hipcc turns `if (ok) v = load` into a branch plus an
+// s_waitcnt vmcnt(0) per load, serialising every memory round trip.  Select the address instead
+// (a always-valid fallback), load unconditionally, then zero.
+template <typename T> __device__ __forceinline__ Vec16<T> ld16_pred(const T* p, const T* safe, bool ok) {
+    Vec16<T> r = ld16<T>(ok ? p : safe);
+    if (!ok) { r.v.x = 0; r.v.y = 0; r.v.z = 0; r.v.w = 0; }
+    return r;
+}
 template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
     Vec16<T> r;
     r.v.x = 0; r.v.y = 0; r.v.z = 0; r.v.w = 0;

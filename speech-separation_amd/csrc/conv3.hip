@@ -57,16 +57,15 @@ __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
             int pp = idx / CPR, ch = idx % CPR;
             int pf = pp / PW, pt = pp - pf * PW;
             int f = f0 - 1 + pf, t = t0 - 1 + pt, ci = ci0 + ch * EPT;
-            Vec16<T> v = zero16<T>();
-            if (f >= 0 && f < p.F && t >= 0 && t < p.T && ci < p.Ci) v = ld16<T>(x + ((int64_t)f * p.T + t) * p.Ci + ci);
+            Vec16<T> v = ld16_pred<T>(x + ((int64_t)f * p.T + t) * p.Ci + ci, x,
+                                      f >= 0 && f < p.F && t >= 0 && t < p.T && ci < p.Ci);
             st16<T>(patch + pp * LDC + ch * EPT, v);
         }
         // ---- stage the weights of this channel chunk: wl[tap][col][ci]
         for (int idx = tid; idx < 9 * BN * CPR; idx += 256) {
             int row = idx / CPR, ch = idx % CPR;
             int tap = row / BN, col = row - tap * BN, ci = ci0 + ch * EPT;
-            Vec16<T> v = zero16<T>();
-            if (ci < p.Ci) v = ld16<T>(wp + ((int64_t)(co0 + col) * 9 + tap) * p.Ci + ci);
+            Vec16<T> v = ld16_pred<T>(wp + ((int64_t)(co0 + col) * 9 + tap) * p.Ci + ci, wp, ci < p.Ci);
             st16<T>(wl + row * LDC + ch * EPT, v);
         }
         __syncthreads();
@@ -221,16 +220,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(Wg3P p) {
         for (int idx = tid; idx < TH * TW * CPR; idx += 256) {
             int pp = idx / CPR, ch = idx % CPR;
             int f = f0 + (pp >> 4), t = t0 + (pp & 15);
-            Vec16<bf16> v = zero16<bf16>();
-            if (f < p.F && t < p.T) v = ld16<bf16>(dy + (((int64_t)b * p.F + f) * p.T + t) * p.Co + co0 + ch * 8);
+            Vec16<bf16> v = ld16_pred<bf16>(dy + (((int64_t)b * p.F + f) * p.T + t) * p.Co + co0 + ch * 8, dy,
+                                            f < p.F && t < p.T);
             st16<bf16>(dyl + pp * LD + ch * 8, v);
         }
         for (int idx = tid; idx < PH * PW * CPR; idx += 256) {
             int pp = idx / CPR, ch = idx % CPR;
             int pf = pp / PW, pt = pp - pf * PW;
             int f = f0 - 1 + pf, t = t0 - 1 + pt;
-            Vec16<bf16> v = zero16<bf16>();
-            if (f >= 0 && f < p.F && t >= 0 && t < p.T) v = ld16<bf16>(x + (((int64_t)b * p.F + f) * p.T + t) * p.Ci + ci0 + ch * 8);
+            Vec16<bf16> v = ld16_pred<bf16>(x + (((int64_t)b * p.F + f) * p.T + t) * p.Ci + ci0 + ch * 8, x,
+                                            f >= 0 && f < p.F && t >= 0 && t < p.T);
             st16<bf16>(xl + pp * LD + ch * 8, v);
         }
         __syncthreads();

@@ -33,86 +33,80 @@ struct TileLoader {
     static constexpr int NIT = (NCH + 255) / 256;
     Vec16<T> regs[NIT];
 
-    // isA: operand A (row stride rs = a_ms, k stride ks = a_ks) else B (rs = b_ns, ks = b_ks)
+    // isA: operand A (row stride rs = a_ms, k stride ks = a_ks) else B (rs = b_ns, ks = b_ks).
+    // Loads are issued UNCONDITIONALLY from a clamped address and zeroed afterwards (ld16_pred): a
+    // branch per load makes hipcc wait vmcnt(0) after each one.  Only partial / misaligned edge
+    // chunks take the scalar path.
     __device__ __forceinline__ void load(const DttGemm& p, bool isA, const T* base, int64_t rs, int64_t ks,
                                          int r0, int rmax, int k0, int kmax, int mode, int z_tap) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int idx = tid + it * 256;
-            Vec16<T> v = zero16<T>();
-            if (idx < NCH) {
-                if (ks == 1 || (isA && mode == 1)) {
-                    // ---- k-contiguous: chunk = EPT consecutive k of one row
-                    int row = idx / (BK / EPT), ch = idx % (BK / EPT);
-                    int gr = r0 + row, gk = k0 + ch * EPT;
-                    if (gr < rmax && gk < kmax) {
-                        const T* src;
-                        bool ok = true;
-                        if (isA && mode == 1) {            // implicit-GEMM conv gather
-                            int tap = gk / p.cCi, ci = gk - tap * p.cCi;
-                            int pix = gr;
-                            int b = pix / (p.cFo * p.cTo); pix -= b * p.cFo * p.cTo;
-                            int fo = pix / p.cTo, to = pix - fo * p.cTo;
-                            int fi, ti;
-                            ok = conv_src(p, fo, to, tap, fi, ti);
-                            src = base + ((int64_t)(b * p.cFi + fi) * p.cTi + ti) * p.cCi + ci;
-                        } else {
-                            src = base + (int64_t)gr * rs + gk;
-                        }
-                        if (ok) {
-                            if (gk + EPT <= kmax && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                                v = ld16<T>(src);
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < EPT; ++e)
-                                    if (gk + e < kmax) v.set(e, ldf(src + e));
-                            }
-                        }
-                    }
-                } else if (rs == 1) {
-                    // ---- row-contiguous: chunk = EPT consecutive rows at one k
-                    int kl = idx / (ROWS / EPT), rc = idx % (ROWS / EPT);
-                    int gr = r0 + rc * EPT, gk = k0 + kl;
-                    if (gr < rmax && gk < kmax) {
-                        const T* src;
-                        bool ok = true;
-                        if (!isA && mode == 1) {           // conv wgrad: k = output pixel
-                            int pix = gk;
-                            int b = pix / (p.cFo * p.cTo); pix -= b * p.cFo * p.cTo;
-                            int fo = pix / p.cTo, to = pix - fo * p.cTo;
-                            int fi, ti;
-                            ok = conv_src(p, fo, to, z_tap, fi, ti);
-                            src = base + ((int64_t)(b * p.cFi + fi) * p.cTi + ti) * p.cCi + gr;
-                        } else if (!isA && mode == 2) {    // LSTM h_{t-1}: shifted row
-                            ok = ((gk / p.sh_heads) % p.sh_L) != p.sh_edge;
-                            src = base + (int64_t)(gk + p.sh_shift) * ks + gr;
-                        } else {
-                            src = base + (int64_t)gk * ks + gr;
-                        }
-                        if (ok) {
-                            if (gr + EPT <= rmax && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                                v = ld16<T>(src);
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < EPT; ++e)
-                                    if (gr + e < rmax) v.set(e, ldf(src + e));
-                            }
-                        }
-                    }
+            const bool live = idx < NCH;
+            if (!live) idx = 0;
+            const T* src = base;
+            bool ok = false;            // element (gr, gk) of the chunk exists
+            int nvalid = 0;             // how many of the EPT elements of the chunk exist
+            int64_t estride = 1;        // stride between the chunk's elements (1: vectorisable)
+            if (ks == 1 || (isA && mode == 1)) {
+                // ---- k-contiguous: chunk = EPT consecutive k of one row
+                int row = idx / (BK / EPT), ch = idx % (BK / EPT);
+                int gr = r0 + row, gk = k0 + ch * EPT;
+                ok = live && gr < rmax && gk < kmax;
+                nvalid = min(EPT, kmax - gk);
+                if (isA && mode == 1) {                // implicit-GEMM conv gather
+                    int gkc = ok ? gk : 0, grc = ok ? gr : 0;
+                    int tap = gkc / p.cCi, ci = gkc - tap * p.cCi;
+                    int pix = grc;
+                    int b = pix / (p.cFo * p.cTo); pix -= b * p.cFo * p.cTo;
+                    int fo = pix / p.cTo, to = pix - fo * p.cTo;
+                    int fi, ti;
+                    ok = conv_src(p, fo, to, tap, fi, ti) && ok;
+                    src = base + ((int64_t)(b * p.cFi + fi) * p.cTi + ti) * p.cCi + ci;
                 } else {
-                    // ---- generic strides: scalar loads, k-major chunk
-                    int row = idx / (BK / EPT), ch = idx % (BK / EPT);
-                    int gr = r0 + row, gk = k0 + ch * EPT;
-                    if (gr < rmax) {
-#pragma unroll
-                        for (int e = 0; e < EPT; ++e)
-                            if (gk + e < kmax) v.set(e, ldf(base + (int64_t)gr * rs + (int64_t)(gk + e) * ks));
-                    }
+                    src = base + (int64_t)gr * rs + gk;
                 }
+            } else if (rs == 1) {
+                // ---- row-contiguous: chunk = EPT consecutive rows at one k
+                int kl = idx / (ROWS / EPT), rc = idx % (ROWS / EPT);
+                int gr = r0 + rc * EPT, gk = k0 + kl;
+                ok = live && gr < rmax && gk < kmax;
+                nvalid = min(EPT, rmax - gr);
+                if (!isA && mode == 1) {               // conv wgrad: k = output pixel
+                    int pix = ok ? gk : 0;
+                    int b = pix / (p.cFo * p.cTo); pix -= b * p.cFo * p.cTo;
+                    int fo = pix / p.cTo, to = pix - fo * p.cTo;
+                    int fi, ti;
+                    ok = conv_src(p, fo, to, z_tap, fi, ti) && ok;
+                    src = base + ((int64_t)(b * p.cFi + fi) * p.cTi + ti) * p.cCi + gr;
+                } else if (!isA && mode == 2) {        // LSTM h_{t-1}: shifted row
+                    ok = ok && ((gk / p.sh_heads) % p.sh_L) != p.sh_edge;
+                    src = base + (int64_t)(gk + p.sh_shift) * ks + gr;
+                } else {
+                    src = base + (int64_t)gk * ks + gr;
+                }
+            } else {
+                // ---- generic strides: scalar loads, k-major chunk
+                int row = idx / (BK / EPT), ch = idx % (BK / EPT);
+                int gr = r0 + row, gk = k0 + ch * EPT;
+                ok = live && gr < rmax && gk < kmax;
+                nvalid = min(EPT, kmax - gk);
+                src = base + (int64_t)gr * rs + (int64_t)gk * ks;
+                estride = ks;
+            }
+            const bool fast = ok && estride == 1 && nvalid >= EPT && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+            Vec16<T> v = ld16_pred<T>(src, base_aligned(base), fast);
+            if (ok && !fast) {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e)
+                    if (e < nvalid) v.set(e, ldf(src + (int64_t)e * estride));
             }
             regs[it] = v;
         }
+    }
+    static __device__ __forceinline__ const T* base_aligned(const T* b) {
+        return reinterpret_cast<const T*>(reinterpret_cast<uintptr_t>(b) & ~(uintptr_t)15);
     }
 
     __device__ __forceinline__ void store(T* lds, bool isA, int64_t rs, int64_t ks, int mode) {

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmP p) {
                 const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
                 const T* src = xg + (row * 2u + dir) * (uint32_t)G4 + jt * 32 + lr;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g][r] = ok ? ldf(src + g * H) : 0.f;
+                for (int g = 0; g < 4; ++g) { const float v = ldf(src + g * H); acc[g][r] = ok ? v : 0.f; }
             }
             // ---- recurrent term h_{t-1} * W_hh^T; W fragments are prefetched one k-step ahead
             if (s > 0) {
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmP p) {
                 float ig = sigmoid_f(acc[0][r]), fg = sigmoid_f(acc[1][r]);
                 float gg = tanh_f(acc[2][r]), og = sigmoid_f(acc[3][r]);
                 const uint32_t rowp = (uint32_t)(ok && s > 0 ? rb[r] + tprev * p.heads : 0);
-                const float cprev = (ok && s > 0) ? p.cst[(rowp * 2u + dir) * (uint32_t)H + j] : 0.f;
+                const float cpl = p.cst[(rowp * 2u + dir) * (uint32_t)H + j];     // unconditional load, then select
+                const float cprev = (ok && s > 0) ? cpl : 0.f;
                 float c = fg * cprev + ig * gg;
                 float h = og * tanh_f(c);
                 stf(hn + nl * LDH + j, h);
@@ -174,20 +175,23 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
                 const bool ok = rb[r] >= 0;
                 const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
                 const uint32_t rowp = (uint32_t)(ok && s > 0 ? rb[r] + tprev * p.heads : 0);
-                float di = 0.f, df = 0.f, dg = 0.f, dog_ = 0.f;
+                // loads are unconditional (row 0 stands in for out-of-range sequences): a branch per
+                // load would serialise the memory round trips
+                const T* gs = gates + (row * 2u + dir) * (uint32_t)G4 + j;
+                const float ig = ldf(gs), fg = ldf(gs + H), gg = ldf(gs + 2 * H), og = ldf(gs + 3 * H);
+                const float c = p.cst[(row * 2u + dir) * (uint32_t)H + j];
+                const float cpl = p.cst[(rowp * 2u + dir) * (uint32_t)H + j];
+                const float cp = (s > 0) ? cpl : 0.f;
+                const float dh = ldf(dy + (row * 2u + dir) * (uint32_t)H + j) + dhr[q][r];
+                const float tc = tanh_f(c);
+                float dog_ = dh * tc * og * (1.f - og);
+                const float dc = dcs[q][r] + dh * og * (1.f - tc * tc);
+                float di = dc * gg * ig * (1.f - ig);
+                float df = dc * cp * fg * (1.f - fg);
+                float dg = dc * ig * (1.f - gg * gg);
+                dcs[q][r] = dc * fg;
+                if (!ok) { di = 0.f; df = 0.f; dg = 0.f; dog_ = 0.f; }
                 if (ok) {
-                    const T* gs = gates + (row * 2u + dir) * (uint32_t)G4 + j;
-                    float ig = ldf(gs), fg = ldf(gs + H), gg = ldf(gs + 2 * H), og = ldf(gs + 3 * H);
-                    float c = p.cst[(row * 2u + dir) * (uint32_t)H + j];
-                    float cp = (s > 0) ? p.cst[(rowp * 2u + dir) * (uint32_t)H + j] : 0.f;
-                    float dh = ldf(dy + (row * 2u + dir) * (uint32_t)H + j) + dhr[q][r];
-                    float tc = tanh_f(c);
-                    dog_ = dh * tc * og * (1.f - og);
-                    float dc = dcs[q][r] + dh * og * (1.f - tc * tc);
-                    di = dc * gg * ig * (1.f - ig);
-                    df = dc * cp * fg * (1.f - fg);
-                    dg = dc * ig * (1.f - gg * gg);
-                    dcs[q][r] = dc * fg;
                     T* gd = dG + (row * 2u + dir) * (uint32_t)G4 + j;
                     stf(gd, di); stf(gd + H, df); stf(gd + 2 * H, dg); stf(gd + 3 * H, dog_);
                 }
@@ -213,11 +217,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
                 for (int idx = threadIdx.x; idx < NB * cpr; idx += blockDim.x) {
                     const int nl = idx / cpr, ch = idx - nl * cpr;
                     const int n = n0 + nl;
-                    Vec16<T> v = zero16<T>();
-                    if (n < p.N) {
-                        const uint32_t row = (uint32_t)((n / p.heads) * p.L * p.heads + (n % p.heads) + t * p.heads);
-                        v = ld16<T>(dG + (row * 2u + dir) * (uint32_t)G4 + g0 * H + ch * EPT);
-                    }
+                    const int nn = n < p.N ? n : 0;
+                    const uint32_t row = (uint32_t)((nn / p.heads) * p.L * p.heads + (nn % p.heads) + t * p.heads);
+                    Vec16<T> v = ld16_pred<T>(dG + (row * 2u + dir) * (uint32_t)G4 + g0 * H + ch * EPT, dG, n < p.N);
                     st16<T>(dgbuf + nl * LDG + ch * EPT, v);
                 }
             }

@@ -12,11 +12,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even
-    return (unsigned short)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 has it in hardware (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16* p) { return bf2f(p->x); }
@@ -43,6 +45,7 @@ template <> struct Vec16<bf16> {
         uint32_t& w = (&v.x)[i >> 1];
         w = (i & 1) ? ((w & 0x0000ffffu) | (b << 16)) : ((w & 0xffff0000u) | b);
     }
+    __device__ __forceinline__ void set2(int i, float lo, float hi) { (&v.x)[i >> 1] = pack_bf16x2(lo, hi); }   // i even
 };
 template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
     Vec16<T> r;
@@ -52,13 +55,15 @@ template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
 template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& r) {
     *reinterpret_cast<decltype(r.v)*>(p) = r.v;
 }
-// Predicated 16-byte load WITHOUT a branch: hipcc turns `if (ok) v = load` into a branch plus an
-// s_waitcnt vmcnt(0) per load, serialising every memory round trip.  Select the address instead
-// (a always-valid fallback), load unconditionally, then zero.
+// Predicated 16-byte load WITHOUT a branch and WITHOUT a select on the loaded data: hipcc turns
+// `if (ok) v = load` into a branch plus an s_waitcnt vmcnt(0) per load, and a select on the result
+// makes it wait for the data right after issuing the load (no overlap with the MFMAs that follow).
+// So the address is selected instead: lanes that are off read 16 bytes of zeros from a device
+// global.  (`safe` is unused, kept for call-site readability.)
+static __device__ uint4 dtt_zero16;          // zero-initialised, never written
 template <typename T> __device__ __forceinline__ Vec16<T> ld16_pred(const T* p, const T* safe, bool ok) {
-    Vec16<T> r = ld16<T>(ok ? p : safe);
-    if (!ok) { r.v.x = 0; r.v.y = 0; r.v.z = 0; r.v.w = 0; }
-    return r;
+    (void)safe;
+    return ld16<T>(ok ? p : reinterpret_cast<const T*>(&dtt_zero16));
 }
 template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
     Vec16<T> r;

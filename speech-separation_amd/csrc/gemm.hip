@@ -3,6 +3,7 @@
 // (dtype, tile config).  64-wide wavefronts, 32x32 MFMA tiles
 // (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32), LDS-staged operands with
 // register prefetch of the next K-tile.
+#include <type_traits>
 #include "common.h"
 #include "../../include/dtt_hip.h"
 
@@ -135,6 +136,191 @@ struct TileLoader {
     }
 };
 
+// Second half of the staged epilogue: one wave writes its parked 32 x (TN*32) fp32 slab as 16-byte
+// chunks of EO outputs (EO = 8: bf16 C, EO = 4: fp32 C), adding the residual (type T) on the way.
+template <typename T, int TN, int EO>
+__device__ __forceinline__ void stage_out(const DttGemm& p, const float* stage, unsigned char* Cb, const T* R,
+                                          int gm0, int gn0, int lane) {
+    constexpr int SW = TN * 32 + 4, CPR = TN * 32 / EO, NIT = 32 * CPR / 64, OSZ = EO == 8 ? 2 : 4;
+    constexpr bool RVEC = Vec16<T>::N == EO;            // residual chunk is one 16-byte vector too
+    Vec16<T> rv[NIT];
+    if (R) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + it * 64, row = idx / CPR, ch = idx % CPR;
+            const int gm = gm0 + row, gn = gn0 + ch * EO;
+            const T* rp = R + (int64_t)gm * p.r_ms + gn;
+            const bool live = gm < p.M && gn < p.N;
+            if constexpr (RVEC) {
+                const bool rfast = live && gn + EO <= p.N && (reinterpret_cast<uintptr_t>(rp) & 15) == 0;
+                rv[it] = ld16_pred<T>(rp, R, rfast);
+                if (live && !rfast) {
+                    for (int e = 0; e < EO; ++e)
+                        if (gn + e < p.N) rv[it].set(e, ldf(rp + e));
+                }
+            } else {
+                rv[it] = zero16<T>();
+#pragma unroll
+                for (int e = 0; e < EO; ++e) {
+                    const bool okr = live && gn + e < p.N;
+                    const float x = ldf(okr ? rp + e : R);
+                    rv[it].set(e, okr ? x : 0.f);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = lane + it * 64, row = idx / CPR, ch = idx % CPR;
+        const int gm = gm0 + row, gn = gn0 + ch * EO;
+        const int nv = min(EO, p.N - gn);
+        const bool live = gm < p.M && nv > 0;
+        float v[EO];
+#pragma unroll
+        for (int q = 0; q < EO / 4; ++q) {
+            const float4 s = *reinterpret_cast<const float4*>(stage + row * SW + ch * EO + q * 4);
+            v[q * 4] = s.x; v[q * 4 + 1] = s.y; v[q * 4 + 2] = s.z; v[q * 4 + 3] = s.w;
+        }
+        if (R) {
+#pragma unroll
+            for (int e = 0; e < EO; ++e) v[e] += rv[it].get(e);
+        }
+        unsigned char* dst = Cb + ((int64_t)gm * p.c_ms + gn) * OSZ;
+        const bool cfast = live && nv == EO && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+        if (cfast) {
+            if constexpr (EO == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                Vec16<bf16> ov;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) ov.set2(e, v[e], v[e + 1]);
+                st16<bf16>(reinterpret_cast<bf16*>(dst), ov);
+            }
+        } else if (live) {
+            for (int e = 0; e < nv; ++e) {
+                if constexpr (EO == 4) reinterpret_cast<float*>(dst)[e] = v[e];
+                else stf(reinterpret_cast<bf16*>(dst) + e, v[e]);
+            }
+        }
+    }
+}
+
+// Fused epilogue shared by the GEMM kernels: alpha, bias, activation, residual, store / atomic add.
+// Must be entered by all waves after a barrier (it reuses the operand LDS as staging).
+template <int ACT> __device__ __forceinline__ float apply_act(float v) {
+    if (ACT == 1) return gelu_f(v);
+    if (ACT == 2) return sigmoid_f(v);
+    return v;
+}
+
+// FASTONLY: the caller guarantees c_ns == 1 and r_ns == 1 (host check), so the element-wise
+// fallback is not even compiled in.
+template <typename T, int WGM, int WGN, int WGK, int TM, int TN, int BM, int BK, bool FASTONLY = false>
+__device__ __forceinline__ void gemm_epilogue(const DttGemm& p, f32x16_t (&acc)[TM][TN], unsigned char* lds_raw,
+                                              int m0, int n0, int bz, int sk) {
+    constexpr int SW = TN * 32 + 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wk = wave % WGK, wn = (wave / WGK) % WGN, wm = wave / (WGK * WGN);
+    const int lr = lane & 31, lh = lane >> 5;
+    // ---- epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)bz * p.c_bs;
+    T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)bz * p.c_bs;
+    const T* R = p.R ? reinterpret_cast<const T*>(p.R) + (int64_t)bz * p.r_bs : nullptr;
+    const bool first_split = (sk == 0);
+    if constexpr (WGK == 1) {
+        // ---- staged epilogue (plain stores, n-contiguous C): each wave parks a 32 x (TN*32) slab of
+        // its accumulators (bias and activation already applied: a lane owns one column) in LDS and
+        // writes it back out as 16-byte chunks along n, with the residual read the same way.  (The
+        // scalar path below costs one 2-byte store per element.)
+        if (!p.atomic && (FASTONLY || (p.c_ns == 1 && (R == nullptr || p.r_ns == 1)))) {
+            float* stage = reinterpret_cast<float*>(lds_raw) + wave * 32 * SW;
+            const bool o4 = p.out_f32 || sizeof(T) == 4;
+            unsigned char* Cb = reinterpret_cast<unsigned char*>(p.C) + (int64_t)bz * p.c_bs * (o4 ? 4 : 2);
+            const float* bp = p.bias_mode ? p.bias : reinterpret_cast<const float*>(&dtt_zero16);
+            float bn[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gn = n0 + (wn * TN + j) * 32 + lr;
+                const float b = bp[(p.bias_mode == 1 && gn < p.N) ? gn : 0];
+                bn[j] = p.bias_mode == 1 ? b : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float bm[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float b = bp[(p.bias_mode == 2 && gm < p.M) ? gm : 0];
+                    bm[r] = p.bias_mode == 2 ? b : 0.f;
+                }
+                auto park = [&](auto act_tag) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SW + j * 32 + lr] =
+                                apply_act<decltype(act_tag)::value>(acc[i][j][r] * p.alpha + bn[j] + bm[r]);
+                };
+                if (p.act == 0) park(std::integral_constant<int, 0>{});
+                else if (p.act == 1) park(std::integral_constant<int, 1>{});
+                else park(std::integral_constant<int, 2>{});
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int gm0 = m0 + (wm * TM + i) * 32, gn0 = n0 + wn * TN * 32;
+                if (o4) stage_out<T, TN, 4>(p, stage, Cb, R, gm0, gn0, lane);
+                else stage_out<T, TN, 8>(p, stage, Cb, R, gm0, gn0, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            return;
+        }
+    }
+    if constexpr (FASTONLY) {
+        // atomic accumulation (split-K partial sums), n-contiguous fp32 C
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gn = n0 + (wn * TN + j) * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = acc[i][j][r] * p.alpha;
+                    if (gn < p.N && gm < p.M) atomicAdd(Cf + (int64_t)gm * p.c_ms + gn, v);
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + (wn * TN + j) * 32 + lr;
+            if (gn >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (gm >= p.M) continue;
+                float v = acc[i][j][r] * p.alpha;
+                if (p.atomic) {
+                    if (first_split && wk == 0 && p.bias_mode) v += p.bias_mode == 1 ? p.bias[gn] : p.bias[gm];
+                    atomicAdd(Cf + (int64_t)gm * p.c_ms + (int64_t)gn * p.c_ns, v);
+                } else {
+                    if (p.bias_mode == 1) v += p.bias[gn];
+                    else if (p.bias_mode == 2) v += p.bias[gm];
+                    if (p.act == 1) v = gelu_f(v);
+                    else if (p.act == 2) v = sigmoid_f(v);
+                    if (R) v += ldf(R + (int64_t)gm * p.r_ms + (int64_t)gn * p.r_ns);
+                    const int64_t o = (int64_t)gm * p.c_ms + (int64_t)gn * p.c_ns;
+                    if (p.out_f32) Cf[o] = v;
+                    else stf(Ct + o, v);
+                }
+            }
+        }
+}
+
 // WGM x WGN x WGK waves (product 4), each wave TM x TN tiles of 32x32.
 template <typename T, int WGM, int WGN, int WGK, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_kernel(const DttGemm p) {
@@ -142,17 +328,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DttGemm p) {
     constexpr int LD = BK + MM<T>::PAD;
     constexpr int ASZ = BM * LD > BK * (BM + 8) ? BM * LD : BK * (BM + 8);
     constexpr int BSZ = BN * LD > BK * (BN + 8) ? BN * LD : BK * (BN + 8);
-    __shared__ __attribute__((aligned(16))) T lds[ASZ + BSZ];
-    T* As = lds;
-    T* Bs = lds + ASZ;
+    constexpr int SW = TN * 32 + 4;                       // staged-epilogue row (floats), see below
+    constexpr int OPB = (ASZ + BSZ) * (int)sizeof(T), STB = WGK == 1 ? 4 * 32 * SW * 4 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[OPB > STB ? OPB : STB];
+    T* As = reinterpret_cast<T*>(lds_raw);
+    T* Bs = As + ASZ;
     // bf16 operands that are contiguous along rows (not k) sit in LDS as [k][rows] and are read transposed
     const bool a_tr = sizeof(T) == 2 && !(p.a_ks == 1 || p.a_mode == 1) && p.a_ms == 1;
     const bool b_tr = sizeof(T) == 2 && p.b_ks != 1 && p.b_ns == 1;
 
+    // XCD-aware workgroup order: the hardware deals consecutive workgroups round-robin to the 8 XCDs
+    // (one L2 each).  Renumber so that consecutive LOGICAL ids -- the tiles of one batch / K-split,
+    // which share operand panels -- run on the same XCD at the same time.
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tm_idx = blockIdx.x / tiles_n, tn_idx = blockIdx.x % tiles_n;
+    const int ntile = gridDim.x;
+    int tile = blockIdx.x, z = blockIdx.y;
+    {
+        const int64_t total = (int64_t)ntile * gridDim.y;
+        const int64_t lin = (int64_t)blockIdx.y * ntile + blockIdx.x;
+        const int64_t per = total / 8;
+        if (lin < per * 8) {
+            const int64_t lg = (lin % 8) * per + lin / 8;
+            tile = (int)(lg % ntile);
+            z = (int)(lg / ntile);
+        }
+    }
+    const int tm_idx = tile / tiles_n, tn_idx = tile % tiles_n;
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
-    const int z = blockIdx.y;
     const int bz = z / p.splitk, sk = z % p.splitk;
 
     // K range of this split (multiples of BK)
@@ -225,37 +427,205 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DttGemm p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)bz * p.c_bs;
-    T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)bz * p.c_bs;
-    const T* R = p.R ? reinterpret_cast<const T*>(p.R) + (int64_t)bz * p.r_bs : nullptr;
-    const bool first_split = (sk == 0);
+    gemm_epilogue<T, WGM, WGN, WGK, TM, TN, BM, BK>(p, acc, lds_raw, m0, n0, bz, sk);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: operand layouts fixed at compile time (KC: contiguous along k, RC: contiguous along
+// rows, RCS: RC with the LSTM row shift), every chunk 16-byte aligned (checked on the host), per-
+// thread source pointers computed once and advanced by a constant per K-tile.  BK = 64 (bf16) so
+// that k-contiguous rows are read 128 bytes at a time.
+enum { OP_KC = 0, OP_RC = 1, OP_RCS = 2 };
+
+template <typename T, int KIND, int ROWS, int BK>
+struct FastLoader {
+    static constexpr int EPT = MM<T>::EPT;
+    static constexpr int LD = BK + MM<T>::PAD;              // KC image [ROWS][LD]
+    static constexpr int LDR = ROWS + 8;                    // RC bf16 image [BK][LDR]
+    static constexpr int NCH = ROWS * BK / EPT;
+    static constexpr int NIT = NCH / 256;
+    static_assert(NCH % 256 == 0, "tile must be a multiple of 256 chunks");
+    const T* src[NIT];
+    const T* safe;
+    int kofs[NIT];          // k offset of the chunk inside the tile
+    bool rok[NIT];
+    int64_t step;           // pointer advance per K-tile
+    Vec16<T> regs[NIT];
+
+    __device__ __forceinline__ void init(const T* base, int64_t rs, int64_t ks, int r0, int rmax, int kbeg, int64_t shift) {
+        safe = base;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (KIND == OP_KC) {
+                const int row = idx / (BK / EPT), ch = idx % (BK / EPT);
+                rok[it] = r0 + row < rmax;
+                kofs[it] = ch * EPT;
+                src[it] = base + (int64_t)(rok[it] ? r0 + row : 0) * rs + kbeg + ch * EPT;
+            } else {
+                const int kl = idx / (ROWS / EPT), rc = idx % (ROWS / EPT);
+                rok[it] = r0 + rc * EPT < rmax;
+                kofs[it] = kl;
+                src[it] = base + ((int64_t)(kbeg + kl) + shift) * ks + (rok[it] ? r0 + rc * EPT : 0);
+            }
+        }
+        step = KIND == OP_KC ? BK : (int64_t)BK * ks;
+    }
+    // k0: global k of the tile start; kmax: exclusive k bound
+    __device__ __forceinline__ void load(const DttGemm& p, int k0, int kmax) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int gn = n0 + (wn * TN + j) * 32 + lr;
-            if (gn >= p.N) continue;
+        for (int it = 0; it < NIT; ++it) {
+            const int gk = k0 + kofs[it];
+            bool ok = rok[it] && gk < kmax;
+            if (KIND == OP_RCS) ok = ok && ((gk / p.sh_heads) % p.sh_L) != p.sh_edge;
+            regs[it] = ld16_pred<T>(src[it], safe, ok);
+            src[it] += step;
+        }
+    }
+    __device__ __forceinline__ void store(T* lds) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (gm >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha;
-                if (p.atomic) {
-                    if (first_split && wk == 0 && p.bias_mode) v += p.bias_mode == 1 ? p.bias[gn] : p.bias[gm];
-                    atomicAdd(Cf + (int64_t)gm * p.c_ms + (int64_t)gn * p.c_ns, v);
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (KIND == OP_KC) {
+                const int row = idx / (BK / EPT), ch = idx % (BK / EPT);
+                st16<T>(lds + row * LD + ch * EPT, regs[it]);
+            } else {
+                const int kl = idx / (ROWS / EPT), rc = idx % (ROWS / EPT);
+                if constexpr (sizeof(T) == 2) {
+                    st16<T>(lds + kl * LDR + rc * EPT, regs[it]);
                 } else {
-                    if (p.bias_mode == 1) v += p.bias[gn];
-                    else if (p.bias_mode == 2) v += p.bias[gm];
-                    if (p.act == 1) v = gelu_f(v);
-                    else if (p.act == 2) v = sigmoid_f(v);
-                    if (R) v += ldf(R + (int64_t)gm * p.r_ms + (int64_t)gn * p.r_ns);
-                    const int64_t o = (int64_t)gm * p.c_ms + (int64_t)gn * p.c_ns;
-                    if (p.out_f32) Cf[o] = v;
-                    else stf(Ct + o, v);
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) *reinterpret_cast<float*>(lds + (rc * EPT + e) * LD + kl) = regs[it].get(e);
                 }
             }
         }
+    }
+    static constexpr int SIZE = (KIND == OP_KC || sizeof(T) == 4) ? ROWS * LD : BK * LDR;
+    // MFMA fragment of the 32-row block rb at k offset kk (a multiple of 16) of the tile
+    static __device__ __forceinline__ typename MM<T>::Frag frag(const T* lds, int rb, int kk, int lane) {
+        if constexpr (sizeof(T) == 2 && KIND != OP_KC) {
+            const bf16* r0 = reinterpret_cast<const bf16*>(lds) + (kk + 8 * (lane >> 5) + ((lane & 15) >> 2)) * LDR + rb * 32 +
+                             16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            return tr_frag(r0, r0 + 4 * LDR);
+        } else {
+            return MM<T>::ldfrag(lds + (rb * 32 + (lane & 31)) * LD + kk + 8 * (lane >> 5));
+        }
+    }
+};
+
+template <typename T, int AK, int BKD, int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(const DttGemm p) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = sizeof(T) == 2 ? 64 : 32;
+    typedef FastLoader<T, AK, BM, BK> LA;
+    typedef FastLoader<T, BKD, BN, BK> LB;
+    constexpr int SW = TN * 32 + 4;
+    constexpr int OPB = (LA::SIZE + LB::SIZE) * (int)sizeof(T), STB = 4 * 32 * SW * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[OPB > STB ? OPB : STB];
+    T* As = reinterpret_cast<T*>(lds_raw);
+    T* Bs = As + LA::SIZE;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int ntile = gridDim.x;
+    int tile = blockIdx.x, z = blockIdx.y;
+    {   // XCD-aware order (see gemm_kernel)
+        const int64_t total = (int64_t)ntile * gridDim.y;
+        const int64_t lin = (int64_t)blockIdx.y * ntile + blockIdx.x;
+        const int64_t per = total / 8;
+        if (lin < per * 8) {
+            const int64_t lg = (lin % 8) * per + lin / 8;
+            tile = (int)(lg % ntile);
+            z = (int)(lg / ntile);
+        }
+    }
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int bz = z / p.splitk, sk = z % p.splitk;
+    const int ktiles = (p.K + BK - 1) / BK;
+    const int per = (ktiles + p.splitk - 1) / p.splitk;
+    const int kt0 = sk * per, kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wn = wave % WGN, wm = wave / WGN;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    LA la;
+    LB lb;
+    la.init(reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.a_bs, p.a_ms, p.a_ks, m0, p.M, kt0 * BK, 0);
+    lb.init(reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.b_bs, p.b_ns, p.b_ks, n0, p.N, kt0 * BK,
+            BKD == OP_RCS ? p.sh_shift : 0);
+    la.load(p, kt0 * BK, p.K);
+    lb.load(p, kt0 * BK, p.K);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        la.store(As);
+        lb.store(Bs);
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            la.load(p, (kt + 1) * BK, p.K);
+            lb.load(p, (kt + 1) * BK, p.K);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            typename MM<T>::Frag af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = LA::frag(As, wm * TM + i, s * 16, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = LB::frag(Bs, wn * TN + j, s * 16, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) MM<T>::mma(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<T, WGM, WGN, 1, TM, TN, BM, BK, true>(p, acc, lds_raw, m0, n0, bz, sk);
+}
+
+template <typename T, int AK, int BKD, int WGM, int WGN, int TM, int TN>
+int launch_fast(const DttGemm& p, hipStream_t st) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), p.batch * p.splitk);
+    hipLaunchKernelGGL((gemm_fast_kernel<T, AK, BKD, WGM, WGN, TM, TN>), grid, dim3(256), 0, st, p);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int AK, int BKD> int dispatch_fast_tile(const DttGemm& p, hipStream_t st) {
+    if (p.N <= 32) return launch_fast<T, AK, BKD, 4, 1, 1, 1>(p, st);
+    if (p.N <= 64) return launch_fast<T, AK, BKD, 2, 2, 2, 1>(p, st);
+    return launch_fast<T, AK, BKD, 2, 2, 2, 2>(p, st);
+}
+
+// returns 1 if the problem does not qualify for the fast path
+template <typename T> int dispatch_fast(const DttGemm& p, hipStream_t st) {
+    constexpr int E = MM<T>::EPT;
+    if (p.a_mode != 0 || (p.b_mode != 0 && p.b_mode != 2)) return 1;
+    if (p.M <= 64) return 1;                                // small-M tiles stay on the generic kernel
+    if (p.c_ns != 1 || (p.R && p.r_ns != 1) || (p.atomic && p.bias_mode)) return 1;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al(p.A) || !al(p.B)) return 1;
+    int ak, bk;
+    if (p.a_ks == 1 && p.a_ms % E == 0 && p.K % E == 0) ak = OP_KC;
+    else if (p.a_ms == 1 && p.a_ks % E == 0 && p.M % E == 0) ak = OP_RC;
+    else return 1;
+    if (p.batch > 1 && (p.a_bs % E != 0 || p.b_bs % E != 0)) return 1;
+    if (p.b_mode == 2) {
+        if (!(p.b_ns == 1 && p.b_ks % E == 0 && p.N % E == 0)) return 1;
+        bk = OP_RCS;
+    } else if (p.b_ks == 1 && p.b_ns % E == 0 && p.K % E == 0) bk = OP_KC;
+    else if (p.b_ns == 1 && p.b_ks % E == 0 && p.N % E == 0) bk = OP_RC;
+    else return 1;
+    if (ak == OP_KC && bk == OP_KC) return dispatch_fast_tile<T, OP_KC, OP_KC>(p, st);
+    if (ak == OP_KC && bk == OP_RC) return dispatch_fast_tile<T, OP_KC, OP_RC>(p, st);
+    if (ak == OP_RC && bk == OP_RC) return dispatch_fast_tile<T, OP_RC, OP_RC>(p, st);
+    if (ak == OP_RC && bk == OP_RCS) return dispatch_fast_tile<T, OP_RC, OP_RCS>(p, st);
+    return 1;
 }
 
 template <typename T, int WGM, int WGN, int WGK, int TM, int TN>
@@ -302,5 +672,7 @@ extern "C" int dtt_gemm(const DttGemm* pp, void* stream) {
     }
     if (p.b_mode == 2) DTT_CHECK(p.sh_heads > 0 && p.sh_L > 0 && p.b_ns == 1, "dtt_gemm: bad shift params");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = p.dtype == 1 ? dispatch_fast<bf16>(p, st) : dispatch_fast<float>(p, st);
+    if (rc != 1) return rc;
     return p.dtype == 1 ? dispatch<bf16>(p, st) : dispatch<float>(p, st);
 }

@@ -346,6 +346,47 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ in, fl
     out[(int64_t)blockIdx.y * W + w] = s;
 }
 
+// Vectorised variant: a thread owns one 16-byte column chunk and every RL-th row of the block's row
+// range (4 loads in flight), row lanes are folded through LDS.  Needs W, ld multiples of the chunk.
+template <typename T>
+__global__ __launch_bounds__(NT) void colsum_vec_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t R,
+                                                        int W, int64_t ld, int64_t rows_per, int CWb) {
+    constexpr int E = Vec16<T>::N;
+    __shared__ float red[NT * E];
+    const int RL = NT / CWb;
+    const int cl = threadIdx.x % CWb, rl = threadIdx.x / CWb;
+    const int chunk = blockIdx.x * CWb + cl;
+    const bool okc = chunk * E < W && rl < RL;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    float s[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] = 0.f;
+    const T* base = in + (okc ? (int64_t)chunk * E : 0);
+    for (int64_t r = r0 + rl; r < r1; r += 4 * RL) {
+        Vec16<T> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t rr = r + (int64_t)u * RL;
+            v[u] = ld16_pred<T>(base + rr * ld, base + r0 * ld, okc && rr < r1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) s[e] += v[u].get(e);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[threadIdx.x * E + e] = s[e];
+    __syncthreads();
+    // thread t < CWb*E sums column (t) of the block over the row lanes
+    for (int c = threadIdx.x; c < CWb * E; c += NT) {
+        const int gw = blockIdx.x * CWb * E + c;
+        if (gw >= W) continue;
+        float a = 0.f;
+        for (int q = 0; q < RL; ++q) a += red[(q * CWb + c / E) * E + (c % E)];
+        out[(int64_t)blockIdx.y * W + gw] = a;
+    }
+}
+
 int ept_of(int dtype) { return dtype ? 8 : 4; }
 
 }  // namespace
@@ -433,6 +474,16 @@ extern "C" int dtt_colsum(const void* in, float* out, int64_t R, int W, int64_t 
                           void* stream) {
     DTT_CHECK(R > 0 && W > 0 && nchunks > 0 && nchunks <= 65535, "dtt_colsum: bad shape");
     int64_t per = (R + nchunks - 1) / nchunks;
+    const int E = ept_of(dtype);
+    if (W % E == 0 && ld % E == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && per >= 8) {
+        int cw = W / E, CWb = 1;
+        while (CWb < cw && CWb < NT) CWb <<= 1;              // power of two <= NT
+        dim3 vgrid((cw + CWb - 1) / CWb, nchunks);
+        if (dtype) hipLaunchKernelGGL(colsum_vec_kernel<bf16>, vgrid, dim3(NT), 0, ST, (const bf16*)in, out, R, W, ld, per, CWb);
+        else hipLaunchKernelGGL(colsum_vec_kernel<float>, vgrid, dim3(NT), 0, ST, (const float*)in, out, R, W, ld, per, CWb);
+        DTT_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid((W + NT - 1) / NT, nchunks);
     if (dtype) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(NT), 0, ST, (const bf16*)in, out, R, W, ld, per);
     else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(NT), 0, ST, (const float*)in, out, R, W, ld, per);

@@ -54,6 +54,13 @@ def conv_wgrad(p_side, q_side, geom, M, N):
     return dwp
 
 
+def _splitk(M, N, K, batch=1):
+    """Split-K factor for an atomically accumulated weight-gradient GEMM: enough workgroups
+    (~2-3 per CU) to fill 256 CUs, no more -- every split adds M*N fp32 atomics."""
+    tiles = -(-M // 128) * -(-N // 128) * batch
+    return int(max(1, min(128, K // 256, round(640 / tiles))))
+
+
 def colsum(x2d, rows, width, ld=None):
     """Deterministic column sums of a [rows][width] matrix -> fp32 [width]."""
     ld = width if ld is None else ld
@@ -297,12 +304,11 @@ class TDF(torch.autograd.Function):
         dx = torch.empty_like(x)
         gemm_raw(A=w1p, B=dhid, C=dx, R=dout, M=Fq, N=N, K=J, batch=B, a_ms=1, a_ks=Fp, a_bs=0, b_ks=N, b_ns=1,
                  b_bs=J * N, c_ms=N, c_ns=1, c_bs=Fq * N, r_ms=N, r_ns=1, r_bs=Fq * N, dtype=d)
-        sk = max(1, min(64, N // 512, max(1, 1024 // B)))
         dw2 = torch.zeros(Fq, J, dtype=F32, device=dev)
-        gemm_raw(A=dout, B=hid, C=dw2, M=Fq, N=J, K=N, batch=B, splitk=sk, a_ms=N, a_ks=1, a_bs=Fq * N, b_ks=1,
+        gemm_raw(A=dout, B=hid, C=dw2, M=Fq, N=J, K=N, batch=B, splitk=_splitk(Fq, J, N, B), a_ms=N, a_ks=1, a_bs=Fq * N, b_ks=1,
                  b_ns=N, b_bs=J * N, c_ms=J, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
         dw1 = torch.zeros(J, Fq, dtype=F32, device=dev)
-        gemm_raw(A=dhid, B=x, C=dw1, M=J, N=Fq, K=N, batch=B, splitk=sk, a_ms=N, a_ks=1, a_bs=J * N, b_ks=1,
+        gemm_raw(A=dhid, B=x, C=dw1, M=J, N=Fq, K=N, batch=B, splitk=_splitk(J, Fq, N, B), a_ms=N, a_ks=1, a_bs=J * N, b_ks=1,
                  b_ns=N, b_bs=Fq * N, c_ms=Fq, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
         ones = torch.ones(N, dtype=x.dtype, device=dev)
         db2 = torch.zeros(Fq, dtype=F32, device=dev)
@@ -393,9 +399,8 @@ class DualPathRNN(torch.autograd.Function):
         dy = _empty((R, 2 * H), dt, dev)
         gemm_raw(A=dout, B=fcw, C=dy, M=R, N=2 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=2 * H, b_ns=1, c_ms=2 * H, c_ns=1,
                  dtype=d)
-        sk = max(1, min(256, R // 1024))
         dfcw = torch.zeros(Cp, 2 * H, dtype=F32, device=dev)
-        gemm_raw(A=dout, B=y, C=dfcw, M=Cp, N=2 * H, K=R, splitk=sk, a_ms=1, a_ks=Cp, b_ks=2 * H, b_ns=1,
+        gemm_raw(A=dout, B=y, C=dfcw, M=Cp, N=2 * H, K=R, splitk=_splitk(Cp, 2 * H, R), a_ms=1, a_ks=Cp, b_ks=2 * H, b_ns=1,
                  c_ms=2 * H, c_ns=1, dtype=d, atomic=1, out_f32=1)
         dfcb = colsum(dout, R, Cp)
         # recurrent backward
@@ -407,12 +412,12 @@ class DualPathRNN(torch.autograd.Function):
         dwhh = []
         for di, (shift, edge) in enumerate(((-heads, 0), (heads, L - 1))):
             g = torch.zeros(G4, H, dtype=F32, device=dev)
-            gemm_raw(A=dG[:, di], B=y[:, di * H:], C=g, M=G4, N=H, K=R, splitk=sk, a_ms=1, a_ks=2 * G4, b_ks=2 * H,
+            gemm_raw(A=dG[:, di], B=y[:, di * H:], C=g, M=G4, N=H, K=R, splitk=_splitk(G4, H, R), a_ms=1, a_ks=2 * G4, b_ks=2 * H,
                      b_ns=1, c_ms=H, c_ns=1, dtype=d, atomic=1, out_f32=1, b_mode=2, sh_shift=shift,
                      sh_heads=heads, sh_L=L, sh_edge=edge)
             dwhh.append(g)
         dwih = torch.zeros(2 * G4, Cp, dtype=F32, device=dev)
-        gemm_raw(A=dG, B=xn, C=dwih, M=2 * G4, N=Cp, K=R, splitk=sk, a_ms=1, a_ks=2 * G4, b_ks=Cp, b_ns=1,
+        gemm_raw(A=dG, B=xn, C=dwih, M=2 * G4, N=Cp, K=R, splitk=_splitk(2 * G4, Cp, R), a_ms=1, a_ks=2 * G4, b_ks=Cp, b_ns=1,
                  c_ms=Cp, c_ns=1, dtype=d, atomic=1, out_f32=1)
         dbias = colsum(dG, R, 2 * G4)
         dxn = _empty((nslab, L, Cc), dt, dev)
@@ -586,7 +591,7 @@ class MaskISTFT(torch.autograd.Function):
                                  ptr(dmask), B, Fq, T, Cc, S, ld, imoff, d, stream_ptr()), "dtt_mask_bwd")
         P = B * Fq * T
         dw = torch.zeros(2 * S, Cc, dtype=F32, device=dev)
-        gemm_raw(A=dmask, B=x, C=dw, M=2 * S, N=Cc, K=P, splitk=max(1, min(512, P // 2048)), a_ms=1, a_ks=2 * S,
+        gemm_raw(A=dmask, B=x, C=dw, M=2 * S, N=Cc, K=P, splitk=_splitk(2 * S, Cc, P), a_ms=1, a_ks=2 * S,
                  b_ks=Cc, b_ns=1, c_ms=Cc, c_ns=1, dtype=d, atomic=1, out_f32=1)
         db = colsum(dmask, P, 2 * S)
         return dx, dw.view(wshape), db, None, None, None, None, None, None
@@ -689,7 +694,7 @@ def _linear_bwd(x2d, w, dy2d, need_dx=True):
         dx = torch.empty_like(x2d)
         gemm_raw(A=dy2d, B=w, C=dx, M=R, N=K, K=N, a_ms=N, a_ks=1, b_ks=K, b_ns=1, c_ms=K, c_ns=1, dtype=d)
     dw = torch.zeros(N, K, dtype=F32, device=x2d.device)
-    gemm_raw(A=dy2d, B=x2d, C=dw, M=N, N=K, K=R, splitk=max(1, min(256, R // 1024)), a_ms=1, a_ks=N, b_ks=K,
+    gemm_raw(A=dy2d, B=x2d, C=dw, M=N, N=K, K=R, splitk=_splitk(N, K, R), a_ms=1, a_ks=N, b_ks=K,
              b_ns=1, c_ms=K, c_ns=1, dtype=d, atomic=1, out_f32=1)
     return dx, dw
 

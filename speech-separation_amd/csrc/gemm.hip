@@ -451,6 +451,8 @@ struct FastLoader {
     bool rok[NIT];
     int64_t step;           // pointer advance per K-tile
     Vec16<T> regs[NIT];
+    int nv[NIT];            // KC with K not a multiple of the chunk: valid elements of the chunk just loaded
+    bool ragged;
 
     __device__ __forceinline__ void init(const T* base, int64_t rs, int64_t ks, int r0, int rmax, int kbeg, int64_t shift) {
         safe = base;
@@ -470,6 +472,7 @@ struct FastLoader {
             }
         }
         step = KIND == OP_KC ? BK : (int64_t)BK * ks;
+        ragged = false;
     }
     // k0: global k of the tile start; kmax: exclusive k bound
     __device__ __forceinline__ void load(const DttGemm& p, int k0, int kmax) {
@@ -478,6 +481,7 @@ struct FastLoader {
             const int gk = k0 + kofs[it];
             bool ok = rok[it] && gk < kmax;
             if (KIND == OP_RCS) ok = ok && ((gk / p.sh_heads) % p.sh_L) != p.sh_edge;
+            if (KIND == OP_KC) nv[it] = kmax - gk;          // >= EPT except in a ragged last chunk (reads row padding)
             regs[it] = ld16_pred<T>(src[it], safe, ok);
             src[it] += step;
         }
@@ -488,6 +492,11 @@ struct FastLoader {
             const int idx = threadIdx.x + it * 256;
             if (KIND == OP_KC) {
                 const int row = idx / (BK / EPT), ch = idx % (BK / EPT);
+                if (ragged && nv[it] < EPT) {               // zero what lies beyond K (padding may hold anything)
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e)
+                        if (e >= nv[it]) regs[it].set(e, 0.f);
+                }
                 st16<T>(lds + row * LD + ch * EPT, regs[it]);
             } else {
                 const int kl = idx / (ROWS / EPT), rc = idx % (ROWS / EPT);
@@ -560,6 +569,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const DttGemm p) {
     la.init(reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.a_bs, p.a_ms, p.a_ks, m0, p.M, kt0 * BK, 0);
     lb.init(reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.b_bs, p.b_ns, p.b_ks, n0, p.N, kt0 * BK,
             BKD == OP_RCS ? p.sh_shift : 0);
+    la.ragged = lb.ragged = (p.K % MM<T>::EPT) != 0;
     la.load(p, kt0 * BK, p.K);
     lb.load(p, kt0 * BK, p.K);
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -597,6 +607,8 @@ int launch_fast(const DttGemm& p, hipStream_t st) {
 }
 
 template <typename T, int AK, int BKD> int dispatch_fast_tile(const DttGemm& p, hipStream_t st) {
+    if (p.M <= 32 && p.N > 32) return launch_fast<T, AK, BKD, 1, 4, 1, 1>(p, st);
+    if (p.M <= 64 && p.N > 64) return launch_fast<T, AK, BKD, 1, 4, 2, 1>(p, st);
     if (p.N <= 32) return launch_fast<T, AK, BKD, 4, 1, 1, 1>(p, st);
     if (p.N <= 64) return launch_fast<T, AK, BKD, 2, 2, 2, 1>(p, st);
     return launch_fast<T, AK, BKD, 2, 2, 2, 2>(p, st);
@@ -606,20 +618,20 @@ template <typename T, int AK, int BKD> int dispatch_fast_tile(const DttGemm& p, 
 template <typename T> int dispatch_fast(const DttGemm& p, hipStream_t st) {
     constexpr int E = MM<T>::EPT;
     if (p.a_mode != 0 || (p.b_mode != 0 && p.b_mode != 2)) return 1;
-    if (p.M <= 64) return 1;                                // small-M tiles stay on the generic kernel
     if (p.c_ns != 1 || (p.R && p.r_ns != 1) || (p.atomic && p.bias_mode)) return 1;
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    auto ru = [](int v) { return (int64_t)((v + E - 1) / E * E); };
     if (!al(p.A) || !al(p.B)) return 1;
     int ak, bk;
-    if (p.a_ks == 1 && p.a_ms % E == 0 && p.K % E == 0) ak = OP_KC;
-    else if (p.a_ms == 1 && p.a_ks % E == 0 && p.M % E == 0) ak = OP_RC;
+    if (p.a_ks == 1 && p.a_ms % E == 0 && p.a_ms >= ru(p.K)) ak = OP_KC;        // ragged K: rows padded to the chunk
+    else if (p.a_ms == 1 && p.a_ks % E == 0 && p.a_ks >= ru(p.M)) ak = OP_RC;   // a ragged last chunk reads row padding
     else return 1;
     if (p.batch > 1 && (p.a_bs % E != 0 || p.b_bs % E != 0)) return 1;
     if (p.b_mode == 2) {
-        if (!(p.b_ns == 1 && p.b_ks % E == 0 && p.N % E == 0)) return 1;
+        if (!(p.b_ns == 1 && p.b_ks % E == 0 && p.b_ks >= ru(p.N))) return 1;
         bk = OP_RCS;
-    } else if (p.b_ks == 1 && p.b_ns % E == 0 && p.K % E == 0) bk = OP_KC;
-    else if (p.b_ns == 1 && p.b_ks % E == 0 && p.N % E == 0) bk = OP_RC;
+    } else if (p.b_ks == 1 && p.b_ns % E == 0 && p.b_ns >= ru(p.K)) bk = OP_KC;
+    else if (p.b_ns == 1 && p.b_ks % E == 0 && p.b_ks >= ru(p.N)) bk = OP_RC;
     else return 1;
     if (ak == OP_KC && bk == OP_KC) return dispatch_fast_tile<T, OP_KC, OP_KC>(p, st);
     if (ak == OP_KC && bk == OP_RC) return dispatch_fast_tile<T, OP_KC, OP_RC>(p, st);

@@ -49,6 +49,54 @@ def test_gemm_nt_nn_tn(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(513, 300, 257), (64, 200, 513), (20, 72, 100), (300, 20, 64), (130, 64, 61)])
+def test_gemm_fast_path_padded_operands(dt, M, N, K):
+    """The compile-time-layout kernels: rows padded to 16 bytes with NaN in the padding (ragged K
+    chunks must be masked, ragged row chunks must never reach C), residual, bias, GELU, fp32 out,
+    batched, and the atomic split-K form."""
+    from dtt_amd._lib import gemm_raw, dtype_code
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    dev = "cuda"
+    pad = lambda v: (v + 15) // 16 * 16
+    Kp, Np, Mp = pad(K), pad(N), pad(M)
+    Bn = 2
+    a = _mk((Bn, M, K), dt, g)
+    b = _mk((Bn, K, N), dt, g)
+    r = _mk((Bn, M, N), dt, g)
+    bias_n, bias_m = torch.randn(N, generator=g), torch.randn(M, generator=g)
+    ref = a.double() @ b.double()
+    nanfill = lambda shape: torch.full(shape, float("nan"), dtype=dt, device=dev)
+    a_kc = nanfill((Bn, M, Kp)); a_kc[:, :, :K] = a.to(dev)               # A[m][k], k contiguous
+    a_rc = nanfill((Bn, K, Mp)); a_rc[:, :, :M] = a.transpose(1, 2).to(dev)  # A[k][m], m contiguous
+    b_kc = nanfill((Bn, N, Kp)); b_kc[:, :, :K] = b.transpose(1, 2).to(dev)  # B[n][k]
+    b_rc = nanfill((Bn, K, Np)); b_rc[:, :, :N] = b.to(dev)               # B[k][n]
+    rp = nanfill((Bn, M, Np)); rp[:, :, :N] = r.to(dev)
+    d = dtype_code(dt)
+    # KC x KC, bias per n, residual
+    c = nanfill((Bn, M, Np))
+    gemm_raw(A=a_kc, B=b_kc, C=c, bias=bias_n.to(dev), R=rp, M=M, N=N, K=K, batch=Bn, a_ms=Kp, a_ks=1, a_bs=M * Kp,
+             b_ks=1, b_ns=Kp, b_bs=N * Kp, c_ms=Np, c_ns=1, c_bs=M * Np, r_ms=Np, r_ns=1, r_bs=M * Np, dtype=d,
+             bias_mode=1)
+    assert rel_err(c[:, :, :N], ref + bias_n.double() + r.double()) < TOL[dt]
+    assert torch.isnan(c[:, :, N:]).all()                    # padding of C untouched
+    # KC x RC, bias per m, GELU, fp32 output
+    c = torch.full((Bn, M, Np), float("nan"), device=dev)
+    gemm_raw(A=a_kc, B=b_rc, C=c, bias=bias_m.to(dev), M=M, N=N, K=K, batch=Bn, a_ms=Kp, a_ks=1, a_bs=M * Kp,
+             b_ks=Np, b_ns=1, b_bs=K * Np, c_ms=Np, c_ns=1, c_bs=M * Np, dtype=d, bias_mode=2, act=1, out_f32=1)
+    assert rel_err(c[:, :, :N], F.gelu(ref + bias_m.double()[:, None])) < TOL[dt]
+    # RC x RC plain store
+    c = nanfill((Bn, M, Np))
+    gemm_raw(A=a_rc, B=b_rc, C=c, M=M, N=N, K=K, batch=Bn, a_ms=1, a_ks=Mp, a_bs=K * Mp, b_ks=Np, b_ns=1,
+             b_bs=K * Np, c_ms=Np, c_ns=1, c_bs=M * Np, dtype=d)
+    assert rel_err(c[:, :, :N], ref) < TOL[dt]
+    # RC x RC, batches and K-splits accumulated atomically into one fp32 C
+    c = torch.zeros(M, N, device=dev)
+    gemm_raw(A=a_rc, B=b_rc, C=c, M=M, N=N, K=K, batch=Bn, splitk=3, a_ms=1, a_ks=Mp, a_bs=K * Mp, b_ks=Np,
+             b_ns=1, b_bs=K * Np, c_ms=N, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
+    assert rel_err(c, ref.sum(0)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gemm_batched_splitk_atomic(dt):
     from dtt_amd._lib import gemm_raw, dtype_code
     g = torch.Generator().manual_seed(5)

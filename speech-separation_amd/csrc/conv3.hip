@@ -20,6 +20,99 @@ struct Conv3P {
     int B, F, T, Ci, Co, tiles_f, tiles_t;
 };
 
+// Shared epilogue.  A wave owns 64 pixels (tile rows 4*wave .. +3) x BN channels in acc[a][j]
+// (lane: channel j*32 + (lane&31), pixels i = (r&3) + 8*(r>>2) + 4*(lane>>5) of half a).  The values
+// (+bias) are parked in a wave-private fp32 LDS slab and leave as 16-byte chunks -- a tile row of 16
+// pixels is one contiguous run of 16*Co elements in the channels-last tensor -- with the residual
+// read the same way.  Also the per-tile InstanceNorm statistics {mean, M2}; all four waves must call.
+template <typename T, int TN>
+__device__ __forceinline__ void conv3_epilogue(const Conv3P& p, f32x16_t (&acc)[2][TN], float* stage,
+                                               int b, int tf, int tt, int co0) {
+    constexpr int BN = 32 * TN, SW = BN + 4, E = Vec16<T>::N, CPP = BN / E, NIT = CPP;   // 64 px * CPP chunks / 64 lanes
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int f0 = tf * TH, t0 = tt * TW;
+    T* y = reinterpret_cast<T*>(p.y) + (int64_t)b * p.F * p.T * p.Co;
+    const T* res = p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)b * p.F * p.T * p.Co : nullptr;
+    const float* bp = p.bias ? p.bias : reinterpret_cast<const float*>(&dtt_zero16);
+    // statistics are accumulated about a pivot (the slab's first pixel, always inside the image when
+    // the slab has any valid pixel) so that sum-of-squares minus square-of-sum does not cancel
+    float bsv[TN], s1[TN], s2[TN], piv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        bsv[j] = bp[p.bias ? co0 + j * 32 + lr : 0];
+        s1[j] = 0.f; s2[j] = 0.f;
+        piv[j] = __shfl(acc[0][j][0] + bsv[j], lr, 64);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int f = f0 + wave * 4 + a * 2 + (i >> 4), t = t0 + (i & 15);
+            const bool ok = f < p.F && t < p.T;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float v = acc[a][j][r] + bsv[j];
+                const float dv = ok ? v - piv[j] : 0.f;
+                s1[j] += dv;
+                s2[j] += dv * dv;
+                stage[(a * 32 + i) * SW + j * 32 + lr] = v;
+            }
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    Vec16<T> rv[NIT];
+    if (res) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = lane + it * 64, px = id / CPP, ch = id % CPP;
+            const int f = f0 + wave * 4 + (px >> 4), t = t0 + (px & 15);
+            rv[it] = ld16_pred<T>(res + ((int64_t)f * p.T + t) * p.Co + co0 + ch * E, res, f < p.F && t < p.T);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int id = lane + it * 64, px = id / CPP, ch = id % CPP;
+        const int f = f0 + wave * 4 + (px >> 4), t = t0 + (px & 15);
+        float v[E];
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            const float4 s = *reinterpret_cast<const float4*>(stage + px * SW + ch * E + q * 4);
+            v[q * 4] = s.x; v[q * 4 + 1] = s.y; v[q * 4 + 2] = s.z; v[q * 4 + 3] = s.w;
+        }
+        if (res) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] += rv[it].get(e);
+        }
+        Vec16<T> ov;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < E; e += 2) ov.set2(e, v[e], v[e + 1]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) ov.set(e, v[e]);
+        }
+        if (f < p.F && t < p.T) st16<T>(y + ((int64_t)f * p.T + t) * p.Co + co0 + ch * E, ov);
+    }
+    if (!p.partial) return;
+    // ---- InstanceNorm statistics {mean, M2} of this wave's slab (4 tile rows), no workgroup barrier:
+    // fp32 sum and sum of squares over <= 64 pixels; the slabs are merged (Chan) by conv_stats_finalize.
+    const int nr = min(4, max(0, p.F - (f0 + wave * 4))), ntv = min(TW, p.T - t0);
+    const float n = (float)(nr * ntv), inv_n = n > 0.f ? 1.f / n : 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+        const float a2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+        if (lh == 0) {
+            const float dm = a1 * inv_n;
+            float2 o = make_float2(piv[j] + dm, fmaxf(a2 - a1 * dm, 0.f));
+            *reinterpret_cast<float2*>(p.partial + (((((int64_t)b * p.tiles_f + tf) * 4 + wave) * p.tiles_t + tt) * p.Co +
+                                                    co0 + j * 32 + lr) * 2) = o;
+        }
+    }
+}
+
 // waves: 4 along M (each 4 tile rows = 64 px, TM = 2), all of BN = 32*TN output channels.
 template <typename T, int TN>
 __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
@@ -27,8 +120,6 @@ __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* patch = reinterpret_cast<T*>(smem);                  // [PH*PW][LDC]
     T* wl = patch + PH * PW * LDC;                          // [9*BN][LDC]
-    __shared__ float red[4][2 * BN];
-    __shared__ float tmean[BN];
 
     const int ntile_n = p.Co / BN;
     int bid = blockIdx.x;
@@ -91,89 +182,128 @@ __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
         }
     }
 
-    // ---- epilogue: lane owns channel co0 + j*32 + lr, 16 pixels per (a) tile
-    T* y = reinterpret_cast<T*>(p.y) + (int64_t)b * p.F * p.T * p.Co;
-    const T* res = p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)b * p.F * p.T * p.Co : nullptr;
-    float bsv[TN];
+    __syncthreads();                                        // operand LDS becomes the output staging area
+    conv3_epilogue<T, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * 64 * (BN + 4), b, tf, tt, co0);
+}
+
+// Specialisation for Ci = Co = 32, bf16 (the full-resolution TFC convs: HBM-bound at 144 flop/byte):
+// persistent workgroups; the 18 KB of weights live in registers for the whole launch; the next tile's
+// patch is prefetched into registers while the current one is in the MFMAs.
+__global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles_per_wg) {
+    constexpr int LDC = 40, NPC = PH * PW * 4, NIT = (NPC + 255) / 256, SW = 36;
+    __shared__ __attribute__((aligned(16))) bf16 patch[PH * PW * LDC];
+    __shared__ __attribute__((aligned(16))) float stage_all[4 * 64 * SW];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const bf16* wp = reinterpret_cast<const bf16*>(p.wp);
+    s16x8_t wf[9][2];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bsv[j] = p.bias ? p.bias[co0 + j * 32 + lr] : 0.f;
-    float s1[TN];
+    for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) s1[j] = 0.f;
+        for (int s = 0; s < 2; ++s) wf[tap][s] = MM<bf16>::ldfrag(wp + (lr * 9 + tap) * 32 + s * 16 + lh * 8);
+
+    const int per_b = p.tiles_f * p.tiles_t, total = p.B * per_b;
+    const int tile0 = blockIdx.x * tiles_per_wg, tile1 = min(total, tile0 + tiles_per_wg);
+    if (tile0 >= tile1) return;
+    Vec16<bf16> pre[NIT];
+    auto prefetch = [&](int tile) {
+        const int b = tile / per_b, rr = tile - b * per_b, tf = rr / p.tiles_t, tt = rr - tf * p.tiles_t;
+        const bf16* x = reinterpret_cast<const bf16*>(p.x) + (int64_t)b * p.F * p.T * 32;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, pp = idx >> 2, ch = idx & 3;
+            const int pf = pp / PW, pt = pp - pf * PW;
+            const int f = tf * TH - 1 + pf, t = tt * TW - 1 + pt;
+            pre[it] = ld16_pred<bf16>(x + ((int64_t)f * p.T + t) * 32 + ch * 8, x,
+                                      idx < NPC && f >= 0 && f < p.F && t >= 0 && t < p.T);
+        }
+    };
+    prefetch(tile0);
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int b = tile / per_b, rr = tile - b * per_b, tf = rr / p.tiles_t, tt = rr - tf * p.tiles_t;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int f = f0 + wave * 4 + a * 2 + (i >> 4), t = t0 + (i & 15);
-            const bool ok = f < p.F && t < p.T;
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < NPC) st16<bf16>(patch + (idx >> 2) * LDC + (idx & 3) * 8, pre[it]);
+        }
+        __syncthreads();
+        if (tile + 1 < tile1) prefetch(tile + 1);
+        f32x16_t acc[2][1];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float v = acc[a][j][r] + bsv[j];
-                acc[a][j][r] = v;
-                if (ok) {
-                    s1[j] += v;
-                    const int64_t o = ((int64_t)f * p.T + t) * p.Co + co0 + j * 32 + lr;
-                    stf(y + o, res ? v + ldf(res + o) : v);
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][0][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int prow = wave * 4 + a * 2 + (lr >> 4) + kh, pcol = (lr & 15) + kw;
+                    const s16x8_t af = MM<bf16>::ldfrag(patch + (prow * PW + pcol) * LDC + s * 16 + lh * 8);
+                    MM<bf16>::mma(af, wf[tap][s], acc[a][0]);
                 }
             }
         }
-    if (!p.partial) return;
-    // ---- per-tile InstanceNorm statistics {mean, M2} per channel
-    const int nf = min(TH, p.F - f0), ntv = min(TW, p.T - t0);
-    const float inv_cnt = 1.f / (float)(nf * ntv);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        float s = s1[j] + __shfl_xor(s1[j], 32, 64);
-        if (lh == 0) red[wave][j * 32 + lr] = s;
-    }
-    __syncthreads();
-    if (tid < BN) tmean[tid] = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) * inv_cnt;
-    __syncthreads();
-    float s2[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) s2[j] = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int f = f0 + wave * 4 + a * 2 + (i >> 4), t = t0 + (i & 15);
-            if (f < p.F && t < p.T) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) { float d = acc[a][j][r] - tmean[j * 32 + lr]; s2[j] += d * d; }
-            }
-        }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        float s = s2[j] + __shfl_xor(s2[j], 32, 64);
-        if (lh == 0) red[wave][BN + j * 32 + lr] = s;
-    }
-    __syncthreads();
-    if (tid < BN) {
-        float* d = p.partial + ((((int64_t)b * p.tiles_f + tf) * p.tiles_t + tt) * p.Co + co0 + tid) * 2;
-        d[0] = tmean[tid];
-        d[1] = red[0][BN + tid] + red[1][BN + tid] + red[2][BN + tid] + red[3][BN + tid];
+        conv3_epilogue<bf16, 1>(p, acc, stage_all + wave * 64 * SW, b, tf, tt, 0);
+        __syncthreads();                                    // patch is free for the next tile
     }
 }
 
-// merge the per-tile partials (Chan) -> stats[b][c] = {mean, rstd}
-__global__ void conv_stats_finalize(const float* __restrict__ partial, float* __restrict__ stats, int F, int T, int C,
-                                    int tiles_f, int tiles_t, float eps) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (c >= C) return;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int tf = 0; tf < tiles_f; ++tf)
-        for (int tt = 0; tt < tiles_t; ++tt) {
-            const float* s = partial + ((((int64_t)b * tiles_f + tf) * tiles_t + tt) * C + c) * 2;
-            float nb = (float)(min(TH, F - tf * TH) * min(TW, T - tt * TW));
-            float d = s[0] - mean, nn = n + nb;
-            mean += d * nb / nn;
-            m2 += s[1] + d * d * n * nb / nn;
-            n = nn;
+// merge the per-slab partials -> stats[b][c] = {mean, rstd}.  One 1024-thread workgroup per (32
+// channels, b); two passes of plain sums (global mean, then M2 about it) -- no serial Chan chain.
+__global__ __launch_bounds__(1024) void conv_stats_finalize(const float* __restrict__ partial, float* __restrict__ stats,
+                                                            int F, int T, int C, int tiles_f, int tiles_t, float eps) {
+    __shared__ float sh[32][33];
+    __shared__ float gmean[32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl, b = blockIdx.y;
+    const int nslab = tiles_f * 4 * tiles_t;
+    const float* base = partial + (int64_t)b * nslab * C * 2 + (c < C ? c : 0) * 2;
+    const float ntot = (float)F * (float)T;
+    float acc = 0.f;
+    for (int s0 = g; s0 < nslab; s0 += 128) {
+        float2 v[4]; float nb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = min(s0 + u * 32, nslab - 1);
+            v[u] = *reinterpret_cast<const float2*>(base + (int64_t)s * C * 2);
+            const int sf = s / tiles_t, tt = s - sf * tiles_t;
+            nb[u] = (s0 + u * 32 < nslab) ? (float)(min(4, max(0, F - sf * 4)) * min(TW, T - tt * TW)) : 0.f;
         }
-    stats[((int64_t)b * C + c) * 2] = mean;
-    stats[((int64_t)b * C + c) * 2 + 1] = rsqrtf(m2 / n + eps);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += nb[u] * v[u].x;
+    }
+    sh[g][cl] = acc;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.f;
+        for (int q = 0; q < 32; ++q) t += sh[q][cl];
+        gmean[cl] = t / ntot;
+    }
+    __syncthreads();
+    const float mean = gmean[cl];
+    acc = 0.f;
+    for (int s0 = g; s0 < nslab; s0 += 128) {
+        float2 v[4]; float nb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = min(s0 + u * 32, nslab - 1);
+            v[u] = *reinterpret_cast<const float2*>(base + (int64_t)s * C * 2);
+            const int sf = s / tiles_t, tt = s - sf * tiles_t;
+            nb[u] = (s0 + u * 32 < nslab) ? (float)(min(4, max(0, F - sf * 4)) * min(TW, T - tt * TW)) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float d = v[u].x - mean; acc += nb[u] > 0.f ? v[u].y + nb[u] * d * d : 0.f; }
+    }
+    sh[g][cl] = acc;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float t = 0.f;
+        for (int q = 0; q < 32; ++q) t += sh[q][cl];
+        stats[((int64_t)b * C + c) * 2] = mean;
+        stats[((int64_t)b * C + c) * 2 + 1] = rsqrtf(t / ntot + eps);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -268,16 +398,27 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(Wg3P p) {
 #define ST reinterpret_cast<hipStream_t>(stream)
 
 // y = conv3x3_same(x, wp [Co][9][Ci]) + bias (+ res); if partial != NULL also the InstanceNorm
-// statistics: partial scratch [B][tiles_f][tiles_t][Co][2], stats [B][Co][2] = {mean, rstd}.
+// statistics: partial scratch [B][4*tiles_f][tiles_t][Co][2], stats [B][Co][2] = {mean, rstd}.
 extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, void* y, const void* res,
                               float* partial, float* stats, int B, int F, int T, int Ci, int Co, float eps, int dtype,
                               void* stream) {
     const int ept = dtype ? 8 : 4;
     DTT_CHECK(B > 0 && F > 0 && T > 0 && Ci % ept == 0 && Co % 32 == 0, "dtt_conv3x3_s1: unsupported Ci=%d Co=%d", Ci, Co);
     Conv3P p{x, wp, bias, y, res, partial, B, F, T, Ci, Co, (F + TH - 1) / TH, (T + TW - 1) / TW};
+    if (dtype == 1 && Ci == 32 && Co == 32) {
+        const int total = B * p.tiles_f * p.tiles_t;
+        const int tpw = max(1, min(16, total / 1024));       // ~4 workgroups per CU at full size
+        hipLaunchKernelGGL(conv3x3_c32_kernel, dim3((total + tpw - 1) / tpw), dim3(256), 0, ST, p, tpw);
+        if (partial)
+            hipLaunchKernelGGL(conv_stats_finalize, dim3((Co + 31) / 32, B), dim3(1024), 0, ST, partial, stats, F, T, Co,
+                               p.tiles_f, p.tiles_t, eps);
+        DTT_LAUNCH_CHECK();
+        return 0;
+    }
     const int tn = (Co % 64 == 0) ? 2 : 1, bn = 32 * tn;
     const int ldc = KC + (dtype ? 8 : 4), es = dtype ? 2 : 4;
     size_t sm = (size_t)(PH * PW + 9 * bn) * ldc * es;
+    sm = max(sm, (size_t)4 * 64 * (bn + 4) * 4);             // output staging overlays the operands
     dim3 grid(p.tiles_f * p.tiles_t * (Co / bn), B);
 #define LAUNCH(TT, TN_) do { auto k = conv3x3_s1_kernel<TT, TN_>; \
         if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
@@ -286,7 +427,7 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
     else { if (tn == 2) LAUNCH(float, 2); else LAUNCH(float, 1); }
 #undef LAUNCH
     if (partial)
-        hipLaunchKernelGGL(conv_stats_finalize, dim3((Co + 127) / 128, B), dim3(128), 0, ST, partial, stats, F, T, Co,
+        hipLaunchKernelGGL(conv_stats_finalize, dim3((Co + 31) / 32, B), dim3(1024), 0, ST, partial, stats, F, T, Co,
                            p.tiles_f, p.tiles_t, eps);
     DTT_LAUNCH_CHECK();
     return 0;

@@ -77,6 +77,27 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// bf16 path: GELU and its derivative from ONE exponential.  erf by Abramowitz-Stegun 7.1.26
+// (|error| < 1.5e-7, far below bf16 resolution): ~16 VALU ops instead of ~50 for erff.  The fp32
+// (parity) path keeps erff.  e = exp(-x^2/2) serves both erf(x/sqrt2) and the Gaussian density.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float h = 0.5f * poly * e;                  // 0.5 * erfc(|x|/sqrt2)
+    cdf = x >= 0.f ? 1.0f - h : h;
+    pdf = 0.39894228040143268f * e;
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x) {
+    if constexpr (sizeof(T) == 4) return gelu_f(x);
+    float c, p; gelu_parts(x, c, p); return x * c;
+}
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) {
+    if constexpr (sizeof(T) == 4) return gelu_grad_f(x);
+    float c, p; gelu_parts(x, c, p); return c + x * p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -87,25 +87,50 @@ __global__ void in_stats_finalize(const float* __restrict__ partial, float* __re
     stats[((int64_t)b * C + c) * 2 + 1] = rsqrtf(m2 / n + eps);
 }
 
-// z[b][fz][tz][c] = gelu((y[b][f][t][c]-mean)*rstd), cropping (Fy,Ty) -> (Fz,Tz)
+// z[b][fz][tz][c] = gelu((y[b][f][t][c]-mean)*rstd), cropping (Fy,Ty) -> (Fz,Tz).
+// grid (pixel chunks, B); a thread keeps one 16-byte channel chunk (its statistics in registers)
+// and walks pixels with four loads in flight.
 template <typename T>
 __global__ __launch_bounds__(NT) void in_gelu_fwd(const T* __restrict__ y, const float* __restrict__ stats,
-                                                  T* __restrict__ z, int B, int Fy, int Ty, int Fz, int Tz, int C) {
-    constexpr int EPT = Vec16<T>::N;
-    const int cpp = C / EPT;
-    const int64_t total = (int64_t)B * Fz * Tz * cpp;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
-        int cq = (int)(i % cpp);
-        int64_t pix = i / cpp;
-        int t = (int)(pix % Tz);
-        int64_t r = pix / Tz;
-        int f = (int)(r % Fz), b = (int)(r / Fz);
-        Vec16<T> v = ld16<T>(y + (((int64_t)b * Fy + f) * Ty + t) * C + cq * EPT);
-        const float* s = stats + ((int64_t)b * C + cq * EPT) * 2;
-        Vec16<T> o;
+                                                  T* __restrict__ z, int Fy, int Ty, int Fz, int Tz, int C, int chunk) {
+    constexpr int EPT = Vec16<T>::N, U = 4;
+    const int cpp = C / EPT, ppi = NT / cpp;
+    const int tid = threadIdx.x, pl = tid / cpp, cq = tid % cpp;
+    if (pl >= ppi) return;
+    const int b = blockIdx.y, Pz = Fz * Tz;
+    const int p0 = blockIdx.x * chunk, p1 = min(Pz, p0 + chunk);
+    float mean[EPT], rstd[EPT];
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) o.set(e, gelu_f((v.get(e) - s[2 * e]) * s[2 * e + 1]));
-        st16<T>(z + pix * C + cq * EPT, o);
+    for (int e = 0; e < EPT; ++e) {
+        mean[e] = stats[((int64_t)b * C + cq * EPT + e) * 2];
+        rstd[e] = stats[((int64_t)b * C + cq * EPT + e) * 2 + 1];
+    }
+    const T* yb = y + (int64_t)b * Fy * Ty * C + cq * EPT;
+    T* zb = z + (int64_t)b * Pz * C + cq * EPT;
+    const bool same = Ty == Tz;
+    for (int p = p0 + pl; p < p1; p += U * ppi) {
+        Vec16<T> v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = p + u * ppi;
+            int src = q;
+            if (!same) { const int f = q / Tz; src = f * Ty + (q - f * Tz); }
+            v[u] = ld16_pred<T>(yb + (int64_t)src * C, yb, q < p1);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = p + u * ppi;
+            Vec16<T> o;
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < EPT; e += 2)
+                    o.set2(e, gelu_t<T>((v[u].get(e) - mean[e]) * rstd[e]), gelu_t<T>((v[u].get(e + 1) - mean[e + 1]) * rstd[e + 1]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) o.set(e, gelu_t<T>((v[u].get(e) - mean[e]) * rstd[e]));
+            }
+            if (q < p1) st16<T>(zb + (int64_t)q * C, o);
+        }
     }
 }
 
@@ -131,19 +156,30 @@ __global__ __launch_bounds__(NT) void in_gelu_bwd_partial(const T* __restrict__ 
         mean[e] = stats[((int64_t)b * C + cq * EPT + e) * 2];
         rstd[e] = stats[((int64_t)b * C + cq * EPT + e) * 2 + 1];
     }
-    if (tid < nact)
-        for (int p = p0 + pl; p < p1; p += ppi) {
-            int f = p / Ty, t = p - f * Ty;
-            if (f >= Fz || t >= Tz) continue;
-            Vec16<T> v = ld16<T>(y + ((int64_t)b * P + p) * C + cq * EPT);
-            Vec16<T> g = ld16<T>(dz + (((int64_t)b * Fz + f) * Tz + t) * C + cq * EPT);
+    if (tid < nact) {
+        constexpr int U = 4;
+        const T* yb = y + (int64_t)b * P * C + cq * EPT;
+        const T* gb = dz + (int64_t)b * Fz * Tz * C + cq * EPT;
+        for (int p = p0 + pl; p < p1; p += U * ppi) {
+            Vec16<T> v[U], g[U];
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                float yh = (v.get(e) - mean[e]) * rstd[e];
-                float d = g.get(e) * gelu_grad_f(yh);
-                s1[e] += d; s2[e] += d * yh;
+            for (int u = 0; u < U; ++u) {
+                const int q = p + u * ppi;
+                const int f = q / Ty, t = q - f * Ty;
+                const bool in = q < p1 && f < Fz && t < Tz;        // dz is zero outside the crop
+                v[u] = ld16_pred<T>(yb + (int64_t)q * C, yb, in);
+                g[u] = ld16_pred<T>(gb + ((int64_t)f * Tz + t) * C, gb, in);
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const float yh = (v[u].get(e) - mean[e]) * rstd[e];
+                    const float d = g[u].get(e) * gelu_grad_t<T>(yh);
+                    s1[e] += d; s2[e] += d * yh;
+                }
         }
+    }
     float* dst = partial + (((int64_t)b * gridDim.x + ck) * C) * 2;
     reduce_channels<EPT>(s1, red, chv, cpp, nact, C);
     for (int c = tid; c < C; c += NT) dst[c * 2] = chv[c];
@@ -165,35 +201,61 @@ __global__ void in_bwd_finalize(const float* __restrict__ partial, float* __rest
     sums[((int64_t)b * C + c) * 2 + 1] = q * inv_n;
 }
 
-// dy = rstd * (dyh - m1 - yh*m2) over the full plane
+// dy = rstd * (dyh - m1 - yh*m2) over the full plane; same thread layout as in_gelu_fwd
 template <typename T>
 __global__ __launch_bounds__(NT) void in_gelu_bwd_apply(const T* __restrict__ y, const T* __restrict__ dz,
                                                         const float* __restrict__ stats,
-                                                        const float* __restrict__ sums, T* __restrict__ dy, int B,
-                                                        int Fy, int Ty, int Fz, int Tz, int C) {
-    constexpr int EPT = Vec16<T>::N;
-    const int cpp = C / EPT;
-    const int64_t total = (int64_t)B * Fy * Ty * cpp;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
-        int cq = (int)(i % cpp);
-        int64_t pix = i / cpp;
-        int t = (int)(pix % Ty);
-        int64_t r = pix / Ty;
-        int f = (int)(r % Fy), b = (int)(r / Fy);
-        Vec16<T> v = ld16<T>(y + pix * C + cq * EPT);
-        const bool in = f < Fz && t < Tz;
-        Vec16<T> g = zero16<T>();
-        if (in) g = ld16<T>(dz + (((int64_t)b * Fz + f) * Tz + t) * C + cq * EPT);
-        const float* s = stats + ((int64_t)b * C + cq * EPT) * 2;
-        const float* m = sums + ((int64_t)b * C + cq * EPT) * 2;
-        Vec16<T> o;
+                                                        const float* __restrict__ sums, T* __restrict__ dy,
+                                                        int Fy, int Ty, int Fz, int Tz, int C, int chunk) {
+    constexpr int EPT = Vec16<T>::N, U = 4;
+    const int cpp = C / EPT, ppi = NT / cpp;
+    const int tid = threadIdx.x, pl = tid / cpp, cq = tid % cpp;
+    if (pl >= ppi) return;
+    const int b = blockIdx.y, P = Fy * Ty;
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    float mean[EPT], rstd[EPT], m1[EPT], m2[EPT];
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            float yh = (v.get(e) - s[2 * e]) * s[2 * e + 1];
-            float d = in ? g.get(e) * gelu_grad_f(yh) : 0.f;
-            o.set(e, s[2 * e + 1] * (d - m[2 * e] - yh * m[2 * e + 1]));
+    for (int e = 0; e < EPT; ++e) {
+        mean[e] = stats[((int64_t)b * C + cq * EPT + e) * 2];
+        rstd[e] = stats[((int64_t)b * C + cq * EPT + e) * 2 + 1];
+        m1[e] = sums[((int64_t)b * C + cq * EPT + e) * 2];
+        m2[e] = sums[((int64_t)b * C + cq * EPT + e) * 2 + 1];
+    }
+    const T* yb = y + (int64_t)b * P * C + cq * EPT;
+    const T* gb = dz + (int64_t)b * Fz * Tz * C + cq * EPT;
+    T* ob = dy + (int64_t)b * P * C + cq * EPT;
+    const bool same = Ty == Tz && Fy == Fz;
+    for (int p = p0 + pl; p < p1; p += U * ppi) {
+        Vec16<T> v[U], g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = p + u * ppi;
+            bool in = q < p1;
+            int64_t gofs = q;
+            if (!same) { const int f = q / Ty, t = q - f * Ty; in = in && f < Fz && t < Tz; gofs = (int64_t)f * Tz + t; }
+            v[u] = ld16_pred<T>(yb + (int64_t)q * C, yb, q < p1);
+            g[u] = ld16_pred<T>(gb + gofs * C, gb, in);           // zero outside the crop
         }
-        st16<T>(dy + pix * C + cq * EPT, o);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = p + u * ppi;
+            float r[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const float yh = (v[u].get(e) - mean[e]) * rstd[e];
+                const float d = g[u].get(e) * gelu_grad_t<T>(yh);
+                r[e] = rstd[e] * (d - m1[e] - yh * m2[e]);
+            }
+            Vec16<T> o;
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < EPT; e += 2) o.set2(e, r[e], r[e + 1]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) o.set(e, r[e]);
+            }
+            if (q < p1) st16<T>(ob + (int64_t)q * C, o);
+        }
     }
 }
 
@@ -389,6 +451,14 @@ __global__ __launch_bounds__(NT) void colsum_vec_kernel(const T* __restrict__ in
 
 int ept_of(int dtype) { return dtype ? 8 : 4; }
 
+// pixels per workgroup for the elementwise IN kernels: >= 8 unrolled sweeps of the block, ~16 workgroups per CU
+int ew_chunk(int B, int P, int cpp) {
+    const int ppi = NT / cpp, want = max(1, 4096 / max(1, B));
+    int ch = (P + want - 1) / want;
+    ch = max(ch, ppi * 4 * 8);
+    return (ch + ppi * 4 - 1) / (ppi * 4) * (ppi * 4);
+}
+
 }  // namespace
 
 #define ST reinterpret_cast<hipStream_t>(stream)
@@ -411,10 +481,11 @@ extern "C" int dtt_in_gelu_fwd(const void* y, const float* stats, void* z, int B
                                int C, int dtype, void* stream) {
     const int ept = ept_of(dtype);
     DTT_CHECK(C % ept == 0 && Fz <= Fy && Tz <= Ty, "dtt_in_gelu_fwd: bad shape");
-    int64_t total = (int64_t)B * Fz * Tz * (C / ept);
-    int grid = (int)(((total + NT - 1) / NT) < 8192 ? ((total + NT - 1) / NT) : 8192);
-    if (dtype) hipLaunchKernelGGL(in_gelu_fwd<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)y, stats, (bf16*)z, B, Fy, Ty, Fz, Tz, C);
-    else hipLaunchKernelGGL(in_gelu_fwd<float>, dim3(grid), dim3(NT), 0, ST, (const float*)y, stats, (float*)z, B, Fy, Ty, Fz, Tz, C);
+    DTT_CHECK(C / ept <= NT, "dtt_in_gelu_fwd: C=%d too wide", C);
+    const int Pz = Fz * Tz, ech = ew_chunk(B, Pz, C / ept);
+    dim3 grid((Pz + ech - 1) / ech, B);
+    if (dtype) hipLaunchKernelGGL(in_gelu_fwd<bf16>, grid, dim3(NT), 0, ST, (const bf16*)y, stats, (bf16*)z, Fy, Ty, Fz, Tz, C, ech);
+    else hipLaunchKernelGGL(in_gelu_fwd<float>, grid, dim3(NT), 0, ST, (const float*)y, stats, (float*)z, Fy, Ty, Fz, Tz, C, ech);
     DTT_LAUNCH_CHECK();
     return 0;
 }
@@ -430,10 +501,10 @@ extern "C" int dtt_in_gelu_bwd(const void* y, const void* dz, const float* stats
     if (dtype) hipLaunchKernelGGL(in_gelu_bwd_partial<bf16>, dim3(nch, B), dim3(NT), sm, ST, (const bf16*)y, (const bf16*)dz, stats, partial, Fy, Ty, Fz, Tz, C, chunk);
     else hipLaunchKernelGGL(in_gelu_bwd_partial<float>, dim3(nch, B), dim3(NT), sm, ST, (const float*)y, (const float*)dz, stats, partial, Fy, Ty, Fz, Tz, C, chunk);
     hipLaunchKernelGGL(in_bwd_finalize, dim3((C + 127) / 128, B), dim3(128), 0, ST, partial, sums, C, nch, 1.f / (float)P);
-    int64_t total = (int64_t)B * P * (C / ept);
-    int grid = (int)(((total + NT - 1) / NT) < 8192 ? ((total + NT - 1) / NT) : 8192);
-    if (dtype) hipLaunchKernelGGL(in_gelu_bwd_apply<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)y, (const bf16*)dz, stats, sums, (bf16*)dy, B, Fy, Ty, Fz, Tz, C);
-    else hipLaunchKernelGGL(in_gelu_bwd_apply<float>, dim3(grid), dim3(NT), 0, ST, (const float*)y, (const float*)dz, stats, sums, (float*)dy, B, Fy, Ty, Fz, Tz, C);
+    const int ech = ew_chunk(B, P, C / ept);
+    dim3 grid((P + ech - 1) / ech, B);
+    if (dtype) hipLaunchKernelGGL(in_gelu_bwd_apply<bf16>, grid, dim3(NT), 0, ST, (const bf16*)y, (const bf16*)dz, stats, sums, (bf16*)dy, Fy, Ty, Fz, Tz, C, ech);
+    else hipLaunchKernelGGL(in_gelu_bwd_apply<float>, grid, dim3(NT), 0, ST, (const float*)y, (const float*)dz, stats, sums, (float*)dy, Fy, Ty, Fz, Tz, C, ech);
     DTT_LAUNCH_CHECK();
     return 0;
 }

@@ -318,8 +318,9 @@ struct Wg3P {
 };
 
 template <int CT>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(Wg3P p) {
+__global__ __launch_bounds__(256, CT == 32 ? 2 : 1) void conv3x3_wgrad_kernel(Wg3P p) {
     constexpr int LD = CT + 8;                               // bf16 elements; rows stay 16-byte aligned
+    constexpr int CPR = CT / 8, NDY = TH * TW * CPR / 256, NX = (PH * PW * CPR + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16* dyl = reinterpret_cast<bf16*>(smem);               // [TH*TW][LD]
     bf16* xl = dyl + TH * TW * LD;                           // [PH*PW][LD]
@@ -328,9 +329,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(Wg3P p) {
     const int wm = (CT == 64) ? (wave >> 1) : 0, wn = (CT == 64) ? (wave & 1) : 0;
     const bf16* dy = reinterpret_cast<const bf16*>(p.dy);
     const bf16* x = reinterpret_cast<const bf16*>(p.x);
-    // lane roles for the transposing read
+    // lane roles for the transposing read: this lane supplies k = 8h + 4j + q of a 16-pixel k-step
     const int g = lane >> 4, h = lane >> 5, q = (lane & 15) >> 2, pq = lane & 3;
     const int colofs = 16 * (g & 1) + 4 * pq;
+    const int kc0 = 8 * h + q, kc1 = kc0 + 4;
 
     f32x16_t acc[9];
 #pragma unroll
@@ -340,46 +342,68 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(Wg3P p) {
 
     const int ntiles = p.B * p.tiles_f * p.tiles_t;
     const int tile0 = blockIdx.x * p.tiles_per_wg, tile1 = min(ntiles, tile0 + p.tiles_per_wg);
-    for (int tile = tile0; tile < tile1; ++tile) {
+    if (tile0 >= tile1) return;
+    // next tile's dy tile and x patch wait in registers while this one is in the MFMAs
+    Vec16<bf16> dyr[NDY], xr[NX];
+    auto prefetch = [&](int tile) {
         int r = tile;
         const int tt = r % p.tiles_t; r /= p.tiles_t;
         const int tf = r % p.tiles_f, b = r / p.tiles_f;
         const int f0 = tf * TH, t0 = tt * TW;
-        if (tile != tile0) __syncthreads();
-        constexpr int CPR = CT / 8;
-        for (int idx = tid; idx < TH * TW * CPR; idx += 256) {
-            int pp = idx / CPR, ch = idx % CPR;
-            int f = f0 + (pp >> 4), t = t0 + (pp & 15);
-            Vec16<bf16> v = ld16_pred<bf16>(dy + (((int64_t)b * p.F + f) * p.T + t) * p.Co + co0 + ch * 8, dy,
-                                            f < p.F && t < p.T);
-            st16<bf16>(dyl + pp * LD + ch * 8, v);
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            const int idx = tid + it * 256, pp = idx / CPR, ch = idx % CPR;
+            const int f = f0 + (pp >> 4), t = t0 + (pp & 15);
+            dyr[it] = ld16_pred<bf16>(dy + (((int64_t)b * p.F + f) * p.T + t) * p.Co + co0 + ch * 8, dy, f < p.F && t < p.T);
         }
-        for (int idx = tid; idx < PH * PW * CPR; idx += 256) {
-            int pp = idx / CPR, ch = idx % CPR;
-            int pf = pp / PW, pt = pp - pf * PW;
-            int f = f0 - 1 + pf, t = t0 - 1 + pt;
-            Vec16<bf16> v = ld16_pred<bf16>(x + (((int64_t)b * p.F + f) * p.T + t) * p.Ci + ci0 + ch * 8, x,
-                                            f >= 0 && f < p.F && t >= 0 && t < p.T);
-            st16<bf16>(xl + pp * LD + ch * 8, v);
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int idx = tid + it * 256, pp = idx / CPR, ch = idx % CPR;
+            const int pf = pp / PW, pt = pp - pf * PW;
+            const int f = f0 - 1 + pf, t = t0 - 1 + pt;
+            xr[it] = ld16_pred<bf16>(x + (((int64_t)b * p.F + f) * p.T + t) * p.Ci + ci0 + ch * 8, x,
+                                     idx < PH * PW * CPR && f >= 0 && f < p.F && t >= 0 && t < p.T);
+        }
+    };
+    prefetch(tile0);
+    // rows of the tile (= k-steps) this wave contracts over
+    const int kr_lo = (CT == 64) ? 0 : wave * 4, kr_hi = (CT == 64) ? TH : wave * 4 + 4;
+    for (int tile = tile0; tile < tile1; ++tile) {
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            const int idx = tid + it * 256;
+            st16<bf16>(dyl + (idx / CPR) * LD + (idx % CPR) * 8, dyr[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < PH * PW * CPR) st16<bf16>(xl + (idx / CPR) * LD + (idx % CPR) * 8, xr[it]);
         }
         __syncthreads();
-        const int kr0 = (CT == 64) ? 0 : wave * 4, kr1 = (CT == 64) ? TH : wave * 4 + 4;
-        for (int kr = kr0; kr < kr1; ++kr) {
-            // one k-step = the 16 pixels of tile row kr; this lane supplies k = 8h + 4j + q
-            const int kc0 = 8 * h + q, kc1 = kc0 + 4;
-            const bf16* a0 = dyl + (kr * 16 + kc0) * LD + wm * 32 + colofs;
-            const bf16* a1 = dyl + (kr * 16 + kc1) * LD + wm * 32 + colofs;
-            s16x8_t af = tr_frag(a0, a1);
+        if (tile + 1 < tile1) prefetch(tile + 1);
+        // Walk the PATCH rows R: the x fragment of (row R, column shift kw) feeds the taps kh = 0..2 of
+        // the output rows kr = R - kh, so each is read from LDS once instead of three times.
+        s16x8_t a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0;     // dy fragments of rows R, R-1, R-2
+        for (int R = kr_lo; R < kr_hi + 2; ++R) {
+            a2 = a1; a1 = a0;
+            if (R < kr_hi) {
+                const bf16* ap = dyl + (R * 16 + kc0) * LD + wm * 32 + colofs;
+                a0 = tr_frag(ap, ap + 4 * LD);
+            }
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap % 3;
-                const bf16* b0 = xl + ((kr + kh) * PW + kc0 + kw) * LD + wn * 32 + colofs;
-                const bf16* b1 = xl + ((kr + kh) * PW + kc1 + kw) * LD + wn * 32 + colofs;
-                s16x8_t bfv = tr_frag(b0, b1);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af),
-                                                                   __builtin_bit_cast(bf16x8_t, bfv), acc[tap], 0, 0, 0);
+            for (int kw = 0; kw < 3; ++kw) {
+                const bf16* bp = xl + (R * PW + kc0 + kw) * LD + wn * 32 + colofs;
+                const s16x8_t bfv = tr_frag(bp, bp + 4 * LD);
+                const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, bfv);
+                if (R < kr_hi)                                   // kh = 0, kr = R
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0), bb, acc[kw], 0, 0, 0);
+                if (R - 1 >= kr_lo && R - 1 < kr_hi)             // kh = 1
+                    acc[3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), bb, acc[3 + kw], 0, 0, 0);
+                if (R - 2 >= kr_lo)                              // kh = 2
+                    acc[6 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), bb, acc[6 + kw], 0, 0, 0);
             }
         }
+        __syncthreads();
     }
     // ---- atomic accumulate: rows = co, cols = ci
     const int lr = lane & 31;
@@ -442,7 +466,10 @@ extern "C" int dtt_conv3x3_wgrad(const void* dy, const void* x, float* dw, int B
     const int ct = (Ci % 64 == 0 && Co % 64 == 0) ? 64 : 32;
     const int ntiles = B * p.tiles_f * p.tiles_t;
     const int combos = (Co / ct) * (Ci / ct);
-    int nsplit = max(1, min(ntiles, (1024 + combos - 1) / combos));
+    // one resident wave of workgroups (1 per CU at CT = 64, 2 at CT = 32): each workgroup ends with
+    // 9*CT*CT/256 atomics per lane, so fewer, longer workgroups beat a finer split
+    const int target = ct == 64 ? 256 : 512;
+    int nsplit = max(1, min(ntiles, (target + combos - 1) / combos));
     p.tiles_per_wg = (ntiles + nsplit - 1) / nsplit;
     nsplit = (ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
     size_t sm = (size_t)(TH * TW + PH * PW) * (ct + 8) * 2;

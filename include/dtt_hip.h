@@ -102,6 +102,23 @@ int dtt_gn_bwd(const void* x, const void* dxn, const void* dres, const float* ga
 /* Deterministic column sums (bias gradients): out[nchunks][W]. */
 int dtt_colsum(const void* in, float* out, int64_t R, int W, int64_t ld, int nchunks, int dtype, void* stream);
 
+/* Fused BiLSTM forward for bf16, H = 256, C' = 128 (the bench configuration): the input projection
+ * x*W_ih^T + b_ih + b_hh of nn.LSTM (reference src/model/DTTNet/modules/latent.py:87-92) is computed
+ * inside the recurrent kernel, so no [rows][2][4H] pre-activation tensor exists.
+ *   xn [rows][Cp], wihp [2][4H/32][Cp/16][64][8], whhp [2][4H/32][H/16][64][8] (MFMA fragment order),
+ *   bias [2][4H] fp32, y [rows][2H].  Saved for dtt_lstm_bwd_blk (NULL: inference):
+ *   gates_blk [2][ceil(N/32)][L][4][H][2][16], cst_blk [2][ceil(N/32)][L][H][2][16] fp32.
+ * Returns 1 without setting an error when the shape is not covered (use dtt_gemm + dtt_lstm_fwd). */
+int dtt_lstm_fwd_fused(const void* xn, const void* wihp, const void* whhp, const float* bias, void* y,
+                       void* gates_blk, float* cst_blk, int N, int L, int heads, int H, int Cp, int dtype,
+                       void* stream);
+
+/* Backward through time over the blocked activations of dtt_lstm_fwd_fused (bf16, H = 256): the
+ * autograd of nn.LSTM in latent.py:87-92.  dy [rows][2H], wpt as for dtt_lstm_bwd, dG [rows][2][4H]
+ * row-major (consumed by dtt_gemm for dW_ih, dW_hh, dx and by dtt_colsum for the biases). */
+int dtt_lstm_bwd_blk(const void* dy, const void* gates_blk, const float* cst_blk, const void* wpt, void* dG, int N,
+                     int L, int heads, int H, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Persistent bidirectional LSTM recurrence, forward and backward through time
  * (nn.LSTM(C', 2C', bidirectional), latent.py:87-92; gate order i,f,g,o).

@@ -236,6 +236,152 @@ __global__ __launch_bounds__(512) void lstm_fwd_stream_kernel(LstmP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16, H = 256 forward with the input projection fused in: per step
+//     G = [x_t | h_{t-1}] * [W_ih | W_hh]^T + b            (K = C' + H)
+// so the [rows][2][4H] pre-activation tensor (545 MB at the bench size) is never written or read and
+// its GEMM disappears.  Both weight matrices are streamed from L2 every step (768 KB per workgroup),
+// register-prefetched several k-steps ahead; x_t is fetched one step ahead by LDS-DMA in MFMA
+// A-fragment order (one 1 KB instruction per k-step, per-lane source rows), shared by the 8 waves.
+// Saved activations use a private blocked layout that both recurrent kernels address as 16-byte
+// vectors in the MFMA accumulator order (lane = hidden column j, 16 sequences of the block):
+//     gates_blk [2 dir][blocks][L][4][H][2][16] bf16      cst_blk [2 dir][blocks][L][H][2][16] fp32
+// y stays row-major ([rows][2H], consumed by GEMMs) and is copied out of the h buffer in LDS.
+struct LstmFP {
+    const void* xn; const void* wihp; const void* whhp; const float* bias;
+    void* y; void* gates; float* cst;
+    int N, L, heads, Cp, nblk;
+};
+
+// TM 32-sequence blocks per workgroup: every streamed weight fragment feeds TM MFMAs (the step is
+// bound by the weight stream, 768 KB per step per CU, so TM = 2 nearly halves the time per sequence).
+// Weight stream: measured, an LDS-DMA ring made the k-loop LDS-bandwidth bound (every weight byte is
+// written to and read back from LDS: 1.7 MB of LDS traffic per step per CU = 5 us).  The fragments
+// are therefore prefetched straight into registers, D k-steps (4 fragments each) ahead; LDS carries
+// only the A operand.  KT % D == 0 keeps the register slots compile-time across time steps.
+template <int KI, int D>
+__global__ __launch_bounds__(512) void lstm_fwd_fused_kernel(LstmFP p) {
+    constexpr int H = 256, NB = 32, LDH = H + 8, KH = 16, KT = KI + KH, G4 = 1024;
+    static_assert(KT % D == 0, "prefetch slots must be static across time steps");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* hbuf = reinterpret_cast<bf16*>(smem);                       // [NB][LDH]
+    bf16* xabuf = hbuf + NB * LDH;                                    // [2][KI] fragments of 512 elements
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int jts = __builtin_amdgcn_readfirstlane(wave);
+    const int dir = blockIdx.y, blk = blockIdx.x, n0 = blk * NB;
+    const int Cp = KI * 16;
+    const char* wih = reinterpret_cast<const char*>(p.wihp) + ((size_t)dir * G4 * Cp + (size_t)jts * KI * 512) * 2;
+    const char* whh = reinterpret_cast<const char*>(p.whhp) + ((size_t)dir * G4 * H + (size_t)jts * KH * 512) * 2;
+    const bf16* xn = reinterpret_cast<const bf16*>(p.xn);
+    const int j = wave * 32 + lr;
+    uint32_t lane16 = lane * 16;
+    // fragment (kk, g) of the concatenated K (W_ih k-steps first, then W_hh): uniform base + lane*16
+    auto wfrag = [&](int kk, int g) -> s16x8_t {
+        asm volatile("" : "+v"(lane16));                   // keep the 96 addresses out of VGPRs
+        const char* sb = kk < KI ? wih + (size_t)(g * (H / 32) * KI + kk) * 1024
+                                 : whh + (size_t)(g * (H / 32) * KH + (kk - KI)) * 1024;
+        return *reinterpret_cast<const s16x8_t*>(sb + lane16);
+    };
+    // x_t in A-fragment order by LDS-DMA: wave w fetches k-step w (lane = row lr, k half lh), one step ahead
+    const int nA = n0 + lr;
+    const bool okA = nA < p.N;
+    const int rbA = okA ? (nA / p.heads) * p.L * p.heads + (nA % p.heads) : 0;
+    auto issue_x = [&](int t, int buf) {
+        if (jts < KI) {
+            const bf16* src = okA ? xn + (size_t)(rbA + t * p.heads) * Cp + jts * 16 + lh * 8
+                                  : reinterpret_cast<const bf16*>(&dtt_zero16);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xabuf + (buf * KI + jts) * 512), 16, 0, 0);
+        }
+    };
+    int rbY[2];                                            // rows of the y copy-out: local row (tid>>5) + 16u
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int n = n0 + (tid >> 5) + 16 * u;
+        rbY[u] = n < p.N ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
+    }
+    for (int i = tid; i < NB * LDH / 8; i += 512) reinterpret_cast<uint4*>(hbuf)[i] = make_uint4(0, 0, 0, 0);   // h_{-1} = 0
+    issue_x(dir ? p.L - 1 : 0, 0);
+    s16x8_t bq[D][4];
+#pragma unroll
+    for (int kk = 0; kk < D; ++kk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[kk][g] = wfrag(kk, g);
+    float bsv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bsv[g] = p.bias[dir * G4 + g * H + j];
+    float cst[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cst[r] = 0.f;
+    __syncthreads();                                       // (drains the x fetch: LDS-DMA counts on vmcnt)
+    const bool save = p.gates != nullptr;                  // gates and cst are saved together
+
+    for (int s = 0; s < p.L; ++s) {
+        const int t = dir ? p.L - 1 - s : s;
+        const bool more = s + 1 < p.L;
+        if (more) issue_x(dir ? t - 1 : t + 1, (s + 1) & 1);          // x of the next step
+        const bf16* xa = xabuf + (s & 1) * KI * 512;
+        f32x16_t acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = bsv[g];
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const s16x8_t af = kk < KI ? *reinterpret_cast<const s16x8_t*>(xa + kk * 512 + lane * 8)
+                                       : MM<bf16>::ldfrag(hbuf + lr * LDH + (kk - KI) * 16 + lh * 8);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) MM<bf16>::mma(af, bq[kk % D][g], acc[g]);
+            if (kk + D < KT || more) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[kk % D][g] = wfrag((kk + D) % KT, g);
+            }
+        }
+        __syncthreads();                                  // every wave has read h_{t-1}
+        // ---- gates, state update; 16-byte stores in accumulator order
+        const size_t slab = ((size_t)dir * p.nblk + blk) * p.L + t;
+        bf16* gd = reinterpret_cast<bf16*>(p.gates) + slab * (4 * H * 32);
+        float* cd = p.cst + slab * (H * 32) + (j * 2 + lh) * 16;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            Vec16<bf16> gv[4];
+            float4 cv[2];
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                float go[4][2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int rr = half * 8 + q + e;
+                    const float ig = sigm_fast(acc[0][rr]), fg = sigm_fast(acc[1][rr]);
+                    const float gg = tanh_fast(acc[2][rr]), og = sigm_fast(acc[3][rr]);
+                    const float c = fg * cst[rr] + ig * gg;
+                    cst[rr] = c;
+                    (&cv[(q + e) >> 2].x)[(q + e) & 3] = c;
+                    const int nl = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                    stf(hbuf + nl * LDH + j, og * tanh_fast(c));
+                    go[0][e] = ig; go[1][e] = fg; go[2][e] = gg; go[3][e] = og;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gv[g].set2(q, go[g][0], go[g][1]);
+            }
+            if (save) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) st16<bf16>(gd + ((g * H + j) * 2 + lh) * 16 + half * 8, gv[g]);
+                *reinterpret_cast<float4*>(cd + half * 8) = cv[0];
+                *reinterpret_cast<float4*>(cd + half * 8 + 4) = cv[1];
+            }
+        }
+        __syncthreads();                                  // h_t complete (and x_{t+1} landed: the barrier drains vmcnt)
+        // ---- y_t rows straight from the h buffer: 16-byte chunks, 32 per row
+        bf16* y = reinterpret_cast<bf16*>(p.y);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int nl = (tid >> 5) + 16 * u, ch = tid & 31;
+            const uint4 v = *reinterpret_cast<const uint4*>(hbuf + nl * LDH + ch * 8);
+            if (rbY[u] >= 0) *reinterpret_cast<uint4*>(y + ((size_t)(rbY[u] + t * p.heads) * 2 + dir) * H + ch * 8) = v;
+        }
+    }
+}
+
 struct LstmBwdP {
     const void* dy;      // [rows][2H] gradient wrt hidden outputs (T)
     const void* gates;   // [rows][2][4H] saved activations (T)
@@ -357,6 +503,150 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16, H = 256 backward through time over the blocked activation layout of lstm_fwd_fused_kernel.
+// Per step: the saved gates / cell states arrive as 16-byte vectors (prefetched one step ahead), dy
+// rows are staged through LDS by cooperative 16-byte loads, the gate gradients go to LDS once (the
+// A operand of dh_{t-1} = dG_t * W_hh and the source of the row-major dG rows, written back as
+// 16-byte stores), and the W_hh fragments (512 KB per step) are register-prefetched D k-steps ahead.
+struct LstmBP {
+    const void* dy; const void* gates; const float* cst; const void* wpt; void* dG;
+    int N, L, heads, nblk;
+};
+
+template <int D>
+__global__ __launch_bounds__(512) void lstm_bwd_blk_kernel(LstmBP p) {
+    constexpr int H = 256, NB = 32, G4 = 1024, LDG = G4 + 8, LDY = H + 8, KS = 64;
+    static_assert(KS % D == 0, "prefetch slots must be static across time steps");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* dgbuf = reinterpret_cast<bf16*>(smem);                      // [NB][LDG]
+    bf16* dybuf = dgbuf + NB * LDG;                                   // [NB][LDY]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int jts = __builtin_amdgcn_readfirstlane(wave);
+    const int dir = blockIdx.y, blk = blockIdx.x, n0 = blk * NB;
+    const int j = wave * 32 + lr;
+    const bf16* dy = reinterpret_cast<const bf16*>(p.dy);
+    const bf16* gates = reinterpret_cast<const bf16*>(p.gates);
+    bf16* dG = reinterpret_cast<bf16*>(p.dG);
+    const char* wpt = reinterpret_cast<const char*>(p.wpt) + ((size_t)dir * G4 * H + (size_t)jts * KS * 512) * 2;
+    uint32_t lane16 = lane * 16;
+    auto wfrag = [&](int k) -> s16x8_t {
+        asm volatile("" : "+v"(lane16));
+        return *reinterpret_cast<const s16x8_t*>(wpt + (size_t)k * 1024 + lane16);
+    };
+    // cooperative row roles: dy rows (32 chunks of 16 bytes per row) and dG rows (128 chunks per row)
+    int rbY[2], rbG[8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int n = n0 + (tid >> 5) + 16 * u;
+        rbY[u] = n < p.N ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int n = n0 + (tid >> 7) + 4 * u;
+        rbG[u] = n < p.N ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
+    }
+    auto slab_of = [&](int t) { return ((size_t)dir * p.nblk + blk) * p.L + t; };
+    auto load_dy = [&](int t, uint4 (&v)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16* src = rbY[u] >= 0 ? dy + ((size_t)(rbY[u] + t * p.heads) * 2 + dir) * H + (tid & 31) * 8
+                                          : reinterpret_cast<const bf16*>(&dtt_zero16);
+            v[u] = *reinterpret_cast<const uint4*>(src);
+        }
+    };
+    auto load_gates = [&](int t, Vec16<bf16> (&gv)[4][2]) {
+        const bf16* gd = gates + slab_of(t) * (4 * H * 32);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            gv[g][0] = ld16<bf16>(gd + ((g * H + j) * 2 + lh) * 16);
+            gv[g][1] = ld16<bf16>(gd + ((g * H + j) * 2 + lh) * 16 + 8);
+        }
+    };
+    auto load_c = [&](int t, float4 (&cv)[4]) {
+        const float* cd = p.cst + slab_of(t) * (H * 32) + (j * 2 + lh) * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cv[q] = *reinterpret_cast<const float4*>(cd + q * 4);
+    };
+
+    float dcs[16];
+    f32x16_t dhr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dcs[r] = 0.f; dhr[r] = 0.f; }
+    const int tl = dir ? 0 : p.L - 1;                      // step processed first
+    uint4 dyv[2];
+    Vec16<bf16> gv[4][2];
+    float4 cv[4], cpv[4], cnx[4];                          // c_t, c_{t-1} (forward order), prefetch
+    load_dy(tl, dyv);
+    load_gates(tl, gv);
+    load_c(tl, cv);
+    if (p.L > 1) load_c(dir ? 1 : p.L - 2, cpv);
+    else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cpv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    s16x8_t bq[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) bq[k] = wfrag(k);
+
+    for (int s = p.L - 1; s >= 0; --s) {
+        const int t = dir ? p.L - 1 - s : s;
+        const int tprev = dir ? t + 1 : t - 1;          // forward-pass predecessor step
+        // dy rows of this step -> LDS
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            *reinterpret_cast<uint4*>(dybuf + ((tid >> 5) + 16 * u) * LDY + (tid & 31) * 8) = dyv[u];
+        __syncthreads();                                  // dybuf ready; dgbuf free (GEMM of the previous step done)
+        if (s > 0) load_dy(tprev, dyv);                   // next step's rows, landed by the time they are staged
+        if (s > 1) load_c(dir ? t + 2 : t - 2, cnx);      // cell state two steps back: next step's c_{t-1}
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float ig = gv[0][r >> 3].get(r & 7), fg = gv[1][r >> 3].get(r & 7);
+            const float gg = gv[2][r >> 3].get(r & 7), og = gv[3][r >> 3].get(r & 7);
+            const float c = (&cv[r >> 2].x)[r & 3], cp = (&cpv[r >> 2].x)[r & 3];
+            const float dh = ldf(dybuf + nl * LDY + j) + dhr[r];
+            const float tc = tanh_fast(c);
+            const float dog_ = dh * tc * og * (1.f - og);
+            const float dc = dcs[r] + dh * og * (1.f - tc * tc);
+            const float di = dc * gg * ig * (1.f - ig);
+            const float df = dc * cp * fg * (1.f - fg);
+            const float dg = dc * ig * (1.f - gg * gg);
+            dcs[r] = dc * fg;
+            bf16* ld = dgbuf + nl * LDG + j;
+            stf(ld, di); stf(ld + H, df); stf(ld + 2 * H, dg); stf(ld + 3 * H, dog_);
+        }
+        if (s > 0) {
+            load_gates(tprev, gv);                        // prefetch the next step's activations
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cv[q] = cpv[q];
+                cpv[q] = s > 1 ? cnx[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();                                  // dG_t complete in LDS
+        // ---- dh_{t-1} = dG_t * W_hh, K = 4H
+        if (s > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dhr[r] = 0.f;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const s16x8_t af = MM<bf16>::ldfrag(dgbuf + lr * LDG + k * 16 + lh * 8);
+                MM<bf16>::mma(af, bq[k % D], dhr);
+                if (k + D < KS || s > 1) bq[k % D] = wfrag((k + D) % KS);
+            }
+        }
+        // ---- dG rows out, row-major [row][dir][4H]: 8 chunks of 16 bytes per thread.  After the GEMM:
+        // vmcnt retires in order, so stores ahead of the weight loads would stall their waits.
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int nl = (tid >> 7) + 4 * u, ch = tid & 127;
+            const uint4 v = *reinterpret_cast<const uint4*>(dgbuf + nl * LDG + ch * 8);
+            if (rbG[u] >= 0) *reinterpret_cast<uint4*>(dG + ((size_t)(rbG[u] + t * p.heads) * 2 + dir) * G4 + ch * 8) = v;
+        }
+    }
+}
+
 template <typename T, int PF>
 int launch_fwd(const LstmP& p, int nw, hipStream_t st) {
     size_t sm = (size_t)2 * 32 * (p.H + MM<T>::PAD) * sizeof(T);
@@ -433,3 +723,42 @@ extern "C" int dtt_lstm_bwd(const void* dy, const void* gates, const float* cst,
     if (np == 2) return launch_bwd<float, 2>(p, nw, st);
     return launch_bwd<float, 4>(p, nw, st);
 }
+
+// Fused forward for bf16, H = 256, C' = 128 (see lstm_fwd_fused_kernel).  gates_blk / cst_blk may be
+// NULL when no backward pass follows.  Returns 1 (no error set) when the shape is not covered: the
+// caller then uses dtt_gemm + dtt_lstm_fwd.
+extern "C" int dtt_lstm_fwd_fused(const void* xn, const void* wihp, const void* whhp, const float* bias, void* y,
+                                  void* gates_blk, float* cst_blk, int N, int L, int heads, int H, int Cp, int dtype,
+                                  void* stream) {
+    if (!(dtype == 1 && H == 256 && Cp == 128)) return 1;
+    DTT_CHECK(N > 0 && L > 0 && heads > 0 && N % heads == 0, "dtt_lstm_fwd_fused: bad shape N=%d L=%d", N, L);
+    DTT_CHECK((int64_t)((N + 31) / 32) * 32 * L * 8 * H < (1LL << 31), "dtt_lstm_fwd_fused: buffers exceed 32-bit offsets");
+    DTT_CHECK((gates_blk == nullptr) == (cst_blk == nullptr), "dtt_lstm_fwd_fused: gates_blk and cst_blk go together");
+    const int nblk = (N + 31) / 32;
+    LstmFP p{xn, wihp, whhp, bias, y, gates_blk, cst_blk, N, L, heads, Cp, nblk};
+    constexpr int KI = 8;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t sm = (size_t)32 * (256 + 8) * 2 + 2 * KI * 1024;
+    auto k = lstm_fwd_fused_kernel<KI, 4>;
+    hipLaunchKernelGGL(k, dim3(nblk, 2), dim3(512), sm, st, p);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward through time over the blocked activations written by dtt_lstm_fwd_fused (bf16, H = 256).
+// dy [rows][2H], wpt [2][H/32][4H/16][64][8] (as dtt_lstm_bwd), dG [rows][2][4H] row-major.
+extern "C" int dtt_lstm_bwd_blk(const void* dy, const void* gates_blk, const float* cst_blk, const void* wpt, void* dG,
+                                int N, int L, int heads, int H, int dtype, void* stream) {
+    DTT_CHECK(dtype == 1 && H == 256, "dtt_lstm_bwd_blk: bf16, H = 256 only (got dtype %d, H %d)", dtype, H);
+    DTT_CHECK(N > 0 && L > 0 && heads > 0 && N % heads == 0, "dtt_lstm_bwd_blk: bad shape N=%d L=%d", N, L);
+    DTT_CHECK(dy && gates_blk && cst_blk && wpt && dG, "dtt_lstm_bwd_blk: null buffer");
+    const int nblk = (N + 31) / 32;
+    LstmBP p{dy, gates_blk, cst_blk, wpt, dG, N, L, heads, nblk};
+    const size_t sm = (size_t)32 * (1024 + 8) * 2 + 32 * (256 + 8) * 2;
+    auto k = lstm_bwd_blk_kernel<8>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(k, dim3(nblk, 2), dim3(512), sm, reinterpret_cast<hipStream_t>(stream), p);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+

@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 
+import os
 import torch
 
 from ._lib import lib, check, stream_ptr, ptr, dtype_code, gemm_raw, DttError
@@ -335,6 +336,21 @@ def _pack_whh_bwd(w, dt):
     return w.view(G4 // 16, 2, 8, H // 32, 32).permute(3, 0, 1, 4, 2).to(dt).contiguous()
 
 
+def _unblock(t, W, N, L, heads):
+    """blocked [2][nblk][L][W/H..] activation layout of the fused LSTM kernels -> row-major [R][2][W]
+    (debug / transition helper: index q = lh*16 + r of the last axis is local sequence
+    (r&3) + 8*(r>>2) + 4*lh)."""
+    nblk = t.shape[1]
+    q = torch.arange(32, device=t.device)
+    lh, r = q // 16, q % 16
+    nl = (r & 3) + 8 * (r >> 2) + 4 * lh
+    inv = torch.empty_like(nl); inv[nl] = q                 # position of local sequence nl in the lane order
+    v = t.view(2, nblk, L, W, 32)[..., inv]                 # [2][nblk][L][W][nl]
+    v = v.permute(1, 4, 2, 0, 3).reshape(nblk * 32, L, 2, W)[:N]         # [n][L][2][W]
+    v = v.view(N // heads, heads, L, 2, W).permute(0, 2, 1, 3, 4).reshape(N * L, 2, W)
+    return v.contiguous()
+
+
 class DualPathRNN(torch.autograd.Function):
     """One TC_FC_RNN over the time axis (along_f=False) or the frequency axis
     (along_f=True) of x [B,F,T,C], heads folded into the sequence batch.
@@ -362,38 +378,54 @@ class DualPathRNN(torch.autograd.Function):
         geo = (nslab, NI, L, Cc, Cp, gs, C.c_int64(OS), C.c_int64(IS), C.c_int64(RS))
         check(lib().dtt_gn_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(xn), ptr(xperm), ptr(gstats), *geo,
                                C.c_float(1e-5), d, stream_ptr()), "dtt_gn_fwd")
-        # input projection, both directions: xg [R][2][4H]
         wih = torch.cat([w_ih, w_ih_r], 0).to(dt).contiguous()                 # [8H][Cp]
         bsum = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r]).contiguous()
-        xg = _empty((R, 8 * H), dt, dev)
-        gemm_raw(A=xn, B=wih, C=xg, bias=bsum, M=R, N=8 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=1, b_ns=Cp,
-                 c_ms=8 * H, c_ns=1, dtype=d, bias_mode=1)
         wp = torch.stack([_pack_whh_fwd(w_hh, dt), _pack_whh_fwd(w_hh_r, dt)]).contiguous()
         y = _empty((R, 2 * H), dt, dev)
         need = any(ctx.needs_input_grad)
-        gates = _empty((R, 2, 4 * H), dt, dev) if need else None
-        cst = _empty((R, 2, H), F32, dev)            # always: the cell state round-trips through it
         N = nslab * heads
-        check(lib().dtt_lstm_fwd(ptr(xg), ptr(wp), ptr(y), ptr(gates), ptr(cst), N, L, heads, H, d, stream_ptr()),
-              "dtt_lstm_fwd")
+        blocked = dt == torch.bfloat16 and H == 256 and Cp == 128
+        if blocked:
+            # fused input projection, activations saved in the kernels' private blocked layout
+            nblk = (N + 31) // 32
+            wihp = torch.stack([_pack_whh_fwd(w_ih, dt), _pack_whh_fwd(w_ih_r, dt)]).contiguous()
+            gates = _empty((2, nblk, L, 4 * H * 32), dt, dev) if need else None
+            cst = _empty((2, nblk, L, H * 32), F32, dev) if need else None
+            rc = lib().dtt_lstm_fwd_fused(ptr(xn), ptr(wihp), ptr(wp), ptr(bsum), ptr(y), ptr(gates), ptr(cst), N, L,
+                                          heads, H, Cp, d, stream_ptr())
+            if rc == 1:
+                raise DttError("dtt_lstm_fwd_fused refused a shape the host side selected")
+            check(rc, "dtt_lstm_fwd_fused")
+        else:
+            # input projection, both directions: xg [R][2][4H]
+            xg = _empty((R, 8 * H), dt, dev)
+            gemm_raw(A=xn, B=wih, C=xg, bias=bsum, M=R, N=8 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=1, b_ns=Cp,
+                     c_ms=8 * H, c_ns=1, dtype=d, bias_mode=1)
+            gates = _empty((R, 2, 4 * H), dt, dev) if need else None
+            cst = _empty((R, 2, H), F32, dev)            # always: the cell state round-trips through it
+            check(lib().dtt_lstm_fwd(ptr(xg), ptr(wp), ptr(y), ptr(gates), ptr(cst), N, L, heads, H, d, stream_ptr()),
+                  "dtt_lstm_fwd")
         fcw = fc_w.to(dt).contiguous()                                         # [Cp][4Cp]
         res = xperm if along_f else x
         out = _empty((nslab, L, Cc), dt, dev)
         gemm_raw(A=y, B=fcw, C=out, bias=fc_b, R=res, M=R, N=Cp, K=2 * H, a_ms=2 * H, a_ks=1, b_ks=1, b_ns=2 * H,
                  c_ms=Cp, c_ns=1, r_ms=Cp, r_ns=1, dtype=d, bias_mode=1)
         ctx.save_for_backward(x, gamma, xn, gstats, wih, w_hh, w_hh_r, y, gates, cst, fcw)
-        ctx.cfg = (heads, along_f, geo, gs)
+        ctx.cfg = (heads, along_f, geo, gs, blocked)
         # along_f: memory order is [B,T,F,C]; the view below is the reference's merge_heads quirk
         return out.view(B, Fq, T, Cc)
 
     @staticmethod
     def backward(ctx, dout):
         x, gamma, xn, gstats, wih, w_hh, w_hh_r, y, gates, cst, fcw = ctx.saved_tensors
-        heads, along_f, geo, gs = ctx.cfg
+        heads, along_f, geo, gs, blocked = ctx.cfg
         nslab, NI, L, Cc, Cp = geo[0], geo[1], geo[2], geo[3], geo[4]
         dt, dev, d = x.dtype, x.device, _dt(x)
         H = w_hh.shape[1]
         R = nslab * L * heads
+        if blocked and os.environ.get("DTT_LSTM_BWD_UNBLOCK") == "1":      # debug: old kernel on converted layouts
+            gates, cst = _unblock(gates, 4 * H, nslab * heads, L, heads), _unblock(cst, H, nslab * heads, L, heads)
+            blocked = False
         dout = dout.contiguous()                       # memory order == rows (outer, step, head)
         # Linear backward
         dy = _empty((R, 2 * H), dt, dev)
@@ -406,8 +438,12 @@ class DualPathRNN(torch.autograd.Function):
         # recurrent backward
         wpt = torch.stack([_pack_whh_bwd(w_hh, dt), _pack_whh_bwd(w_hh_r, dt)]).contiguous()
         dG = _empty((R, 2, 4 * H), dt, dev)
-        check(lib().dtt_lstm_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), nslab * heads, L, heads, H, d,
-                                 stream_ptr()), "dtt_lstm_bwd")
+        if blocked:
+            check(lib().dtt_lstm_bwd_blk(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), nslab * heads, L, heads, H,
+                                         d, stream_ptr()), "dtt_lstm_bwd_blk")
+        else:
+            check(lib().dtt_lstm_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), nslab * heads, L, heads, H, d,
+                                     stream_ptr()), "dtt_lstm_bwd")
         G4 = 4 * H
         dwhh = []
         for di, (shift, edge) in enumerate(((-heads, 0), (heads, L - 1))):

@@ -218,32 +218,52 @@ def main():
         dist.destroy_process_group()
 
 
-def dominant_kernel_roofline(B, precision, dev):
-    """Time the dominant kernel (the implicit-GEMM 3x3 conv at the full-resolution U-Net level,
-    32 -> 32 channels on [B,513,126]) with events on the stream it is launched on."""
-    from dtt_amd import ops
-    dt = torch.bfloat16 if precision == "bf16" else torch.float32
-    Fq, T, Cc = 513, 126, 32
+def _time_conv(ops, B, Fq, T, Cc, dt, dev, n=20):
     x = torch.randn(B, Fq, T, Cc, device=dev).to(dt)
-    w = (torch.randn(Cc, Cc, 3, 3, device=dev) / 17.0)
+    w = (torch.randn(Cc, Cc, 3, 3, device=dev) / (3.0 * Cc ** 0.5))
     bias = torch.zeros(Cc, device=dev)
     wp = ops._pack_fwd(w, "s1", dt)
     for _ in range(3):
         ops.conv3x3_s1(x, wp, bias, want_stats=True)
-    n = 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    e0.record()                      # torch's current stream == the stream dtt_conv3x3_s1 launches on
     for _ in range(n):
         ops.conv3x3_s1(x, wp, bias, want_stats=True)
     e1.record()
     torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / n / 1e3
+    return e0.elapsed_time(e1) / n / 1e3
+
+
+def dominant_kernel_roofline(B, precision, dev):
+    """The kernel with the largest share of the step (rocprofv3, profiles/): the dedicated 3x3 conv
+    conv3x3_s1_kernel<bf16,2> (+ fused InstanceNorm statistics), 70 launches per step over U-Net
+    levels 1-3, each 76 GFLOP.  Timed here at the level-1 shape (64 -> 64 channels on [B,257,63]) with
+    events on the launch stream; the events also cover the 11 us conv_stats_finalize launch that
+    dtt_conv3x3_s1 issues behind it, so `achieved` is slightly conservative.  At 288 flop/byte the
+    kernel sits at the MFMA side of the ridge (2500 TF / 8 TB/s = 312).  `also` reports the
+    full-resolution 32 -> 32 kernel (conv3x3_c32_kernel), which is HBM-bound (144 flop/byte)."""
+    from dtt_amd import ops
+    dt = torch.bfloat16 if precision == "bf16" else torch.float32
+    es = 2 if precision == "bf16" else 4
+    Fq, T, Cc = 257, 63, 64
+    sec = _time_conv(ops, B, Fq, T, Cc, dt, dev)
     flops = 2.0 * B * Fq * T * Cc * 9 * Cc
     achieved = flops / sec / 1e12
-    return {"kernel": "conv3x3_s1_kernel (conv3x3 32->32 @ [B,513,126] + fused InstanceNorm statistics; 14 fwd + 14 dgrad launches/step)",
+    sec0 = _time_conv(ops, B, 513, 126, 32, dt, dev)
+    bytes0 = 2.0 * B * 513 * 126 * 32 * es                # read x + write y once
+    return {"kernel": "conv3x3_s1_kernel<bf16,2> (conv3x3 64->64 @ [B,257,63] + fused InstanceNorm statistics; "
+                      "70 launches/step over levels 1-3, 76 GFLOP each)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "avg_launch_us": round(sec * 1e6, 1), "flops_per_launch": flops}
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2: gfx950) / WRITE_SIZE passes at this
+            # exact shape (profiles/r01b_pmc_conv_traffic.txt); algorithmic bytes are 265.3e6
+            "traffic": 308.2e6 if (B == 64 and precision == "bf16") else None,
+            "avg_launch_us": round(sec * 1e6, 1), "flops_per_launch": flops,
+            "also": {"kernel": "conv3x3_c32_kernel (conv3x3 32->32 @ [B,513,126], 33 launches/step)", "bound": "hbm",
+                     "achieved": round(bytes0 / sec0 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(bytes0 / sec0 / 8e12, 4), "avg_launch_us": round(sec0 * 1e6, 1),
+                     "traffic": 582.9e6 if (B == 64 and precision == "bf16") else None,
+                     "bytes_per_launch": bytes0}}
 
 
 if __name__ == "__main__":

@@ -59,6 +59,13 @@ typedef struct DttGemm {
     int32_t a_mode, b_mode;
     int32_t cB, cFi, cTi, cCi, cFo, cTo, cstride, ctrans;   /* conv geometry     */
     int32_t sh_shift, sh_heads, sh_L, sh_edge;
+    /* transposed conv (ctrans = 1) by output parity: 0 = all pixels, all nine taps (7 of 9 products
+     * are structural zeros on average); 1 + 2*pf + pt = only the output pixels (fo, to) with
+     * fo%2 == pf, to%2 == pt: M = B * ceil((cFo-pf)/2) * ceil((cTo-pt)/2), K = (pf?2:1)*(pt?2:1)*cCi
+     * with the taps kh in (pf ? {0,2} : {1}), kw likewise; C rows are the pixels' rows of the full
+     * [B][cFo][cTo] output (c_ms = row stride of that tensor)                                  */
+    int32_t cphase;
+    int32_t reserved_;
 } DttGemm;
 int dtt_gemm(const DttGemm* p, void* stream);
 

@@ -22,6 +22,22 @@ __device__ __forceinline__ bool conv_src(const DttGemm& p, int fo, int to, int t
     return a >= 0 && b >= 0 && !(a & 1) && !(b & 1) && fi < p.cFi && ti < p.cTi;
 }
 
+// Output-parity form of the transposed conv (DttGemm::cphase): GEMM row gm -> output pixel, and the
+// row of C (= pixel index in the full [B][cFo][cTo] plane) it is stored to.
+__device__ __forceinline__ void phase_dims(const DttGemm& p, int& pf, int& pt, int& Fp, int& Tp) {
+    const int ph = p.cphase - 1;
+    pf = ph >> 1; pt = ph & 1;
+    Fp = (p.cFo - pf + 1) >> 1; Tp = (p.cTo - pt + 1) >> 1;
+}
+__device__ __forceinline__ int64_t c_row(const DttGemm& p, int gm) {
+    if (!p.cphase) return gm;
+    int pf, pt, Fp, Tp;
+    phase_dims(p, pf, pt, Fp, Tp);
+    int b = gm / (Fp * Tp), r = gm - b * Fp * Tp;
+    int i = r / Tp, jx = r - i * Tp;
+    return ((int64_t)b * p.cFo + 2 * i + pf) * p.cTo + 2 * jx + pt;
+}
+
 // Operand tile loader.  The LDS image is always [ROWS][BK + PAD], k contiguous.
 // A tile: rows = m.  B tile: rows = n.  `contig_k` = the operand is contiguous
 // along k (vector loads along k), else contiguous along rows (vector loads along
@@ -60,10 +76,21 @@ struct TileLoader {
                     int gkc = ok ? gk : 0, grc = ok ? gr : 0;
                     int tap = gkc / p.cCi, ci = gkc - tap * p.cCi;
                     int pix = grc;
-                    int b = pix / (p.cFo * p.cTo); pix -= b * p.cFo * p.cTo;
-                    int fo = pix / p.cTo, to = pix - fo * p.cTo;
-                    int fi, ti;
-                    ok = conv_src(p, fo, to, tap, fi, ti) && ok;
+                    int b, fi, ti;
+                    if (p.cphase) {
+                        int pf, pt, Fp, Tp;
+                        phase_dims(p, pf, pt, Fp, Tp);
+                        b = pix / (Fp * Tp); pix -= b * Fp * Tp;
+                        const int i = pix / Tp, jx = pix - i * Tp;
+                        const int nkw = pt ? 2 : 1, ih = tap / nkw, iw = tap - ih * nkw;
+                        const int a = 2 * i + pf + 1 - (pf ? 2 * ih : 1), bb = 2 * jx + pt + 1 - (pt ? 2 * iw : 1);
+                        fi = a >> 1; ti = bb >> 1;          // a, bb are even by construction
+                        ok = ok && a >= 0 && bb >= 0 && fi < p.cFi && ti < p.cTi;
+                    } else {
+                        b = pix / (p.cFo * p.cTo); pix -= b * p.cFo * p.cTo;
+                        int fo = pix / p.cTo, to = pix - fo * p.cTo;
+                        ok = conv_src(p, fo, to, tap, fi, ti) && ok;
+                    }
                     src = base + ((int64_t)(b * p.cFi + fi) * p.cTi + ti) * p.cCi + ci;
                 } else {
                     src = base + (int64_t)gr * rs + gk;
@@ -185,7 +212,7 @@ __device__ __forceinline__ void stage_out(const DttGemm& p, const float* stage, 
 #pragma unroll
             for (int e = 0; e < EO; ++e) v[e] += rv[it].get(e);
         }
-        unsigned char* dst = Cb + ((int64_t)gm * p.c_ms + gn) * OSZ;
+        unsigned char* dst = Cb + (c_row(p, gm) * p.c_ms + gn) * OSZ;
         const bool cfast = live && nv == EO && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
         if (cfast) {
             if constexpr (EO == 4) {
@@ -313,7 +340,7 @@ __device__ __forceinline__ void gemm_epilogue(const DttGemm& p, f32x16_t (&acc)[
                     if (p.act == 1) v = gelu_f(v);
                     else if (p.act == 2) v = sigmoid_f(v);
                     if (R) v += ldf(R + (int64_t)gm * p.r_ms + (int64_t)gn * p.r_ns);
-                    const int64_t o = (int64_t)gm * p.c_ms + (int64_t)gn * p.c_ns;
+                    const int64_t o = c_row(p, gm) * p.c_ms + (int64_t)gn * p.c_ns;
                     if (p.out_f32) Cf[o] = v;
                     else stf(Ct + o, v);
                 }
@@ -623,15 +650,16 @@ template <typename T> int dispatch_fast(const DttGemm& p, hipStream_t st) {
     auto ru = [](int v) { return (int64_t)((v + E - 1) / E * E); };
     if (!al(p.A) || !al(p.B)) return 1;
     int ak, bk;
-    if (p.a_ks == 1 && p.a_ms % E == 0 && p.a_ms >= ru(p.K)) ak = OP_KC;        // ragged K: rows padded to the chunk
-    else if (p.a_ms == 1 && p.a_ks % E == 0 && p.a_ks >= ru(p.M)) ak = OP_RC;   // a ragged last chunk reads row padding
+    const bool kfull = p.K % E == 0;                       // else the ragged last chunk must lie in row padding
+    if (p.a_ks == 1 && p.a_ms % E == 0 && (kfull || p.a_ms >= ru(p.K))) ak = OP_KC;
+    else if (p.a_ms == 1 && p.a_ks % E == 0 && (p.M % E == 0 || p.a_ks >= ru(p.M))) ak = OP_RC;   // ragged: reads row padding
     else return 1;
     if (p.batch > 1 && (p.a_bs % E != 0 || p.b_bs % E != 0)) return 1;
     if (p.b_mode == 2) {
-        if (!(p.b_ns == 1 && p.b_ks % E == 0 && p.b_ks >= ru(p.N))) return 1;
+        if (!(p.b_ns == 1 && p.b_ks % E == 0 && (p.N % E == 0 || p.b_ks >= ru(p.N)))) return 1;
         bk = OP_RCS;
-    } else if (p.b_ks == 1 && p.b_ns % E == 0 && p.b_ns >= ru(p.K)) bk = OP_KC;
-    else if (p.b_ns == 1 && p.b_ks % E == 0 && p.b_ks >= ru(p.N)) bk = OP_RC;
+    } else if (p.b_ks == 1 && p.b_ns % E == 0 && (kfull || p.b_ns >= ru(p.K))) bk = OP_KC;
+    else if (p.b_ns == 1 && p.b_ks % E == 0 && (p.N % E == 0 || p.b_ks >= ru(p.N))) bk = OP_RC;
     else return 1;
     if (ak == OP_KC && bk == OP_KC) return dispatch_fast_tile<T, OP_KC, OP_KC>(p, st);
     if (ak == OP_KC && bk == OP_RC) return dispatch_fast_tile<T, OP_KC, OP_RC>(p, st);
@@ -671,7 +699,15 @@ extern "C" int dtt_gemm(const DttGemm* pp, void* stream) {
     DTT_CHECK(p.splitk == 1 || p.atomic, "dtt_gemm: split-K needs atomic accumulation");
     DTT_CHECK(!p.atomic || (p.act == 0 && p.R == nullptr), "dtt_gemm: atomic mode has no act/residual");
     DTT_CHECK((int64_t)p.batch * p.splitk <= 65535, "dtt_gemm: grid.y too large");
-    if (p.a_mode == 1) {
+    if (p.a_mode == 1 && p.cphase) {
+        const int pf = (p.cphase - 1) >> 1, pt = (p.cphase - 1) & 1;
+        DTT_CHECK(p.cphase >= 1 && p.cphase <= 4 && p.ctrans && p.cstride == 2 && !p.atomic && p.R == nullptr,
+                  "dtt_gemm: cphase needs a plain-store transposed stride-2 conv");
+        DTT_CHECK(p.K == (pf ? 2 : 1) * (pt ? 2 : 1) * p.cCi &&
+                      p.M == p.cB * ((p.cFo - pf + 1) / 2) * ((p.cTo - pt + 1) / 2),
+                  "dtt_gemm: parity-phase geometry mismatch (K=%d M=%d)", p.K, p.M);
+        DTT_CHECK(p.cCi % (p.dtype ? 8 : 4) == 0, "dtt_gemm: conv Ci=%d must be a multiple of 16 bytes", p.cCi);
+    } else if (p.a_mode == 1) {
         DTT_CHECK(p.K == 9 * p.cCi && p.M == p.cB * p.cFo * p.cTo, "dtt_gemm: conv geometry mismatch (K=%d Ci=%d M=%d)",
                   p.K, p.cCi, p.M);
         DTT_CHECK(p.cCi % (p.dtype ? 8 : 4) == 0, "dtt_gemm: conv Ci=%d must be a multiple of 16 bytes", p.cCi);

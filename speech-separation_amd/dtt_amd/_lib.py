@@ -70,6 +70,7 @@ class DttGemm(C.Structure):
         ("cB", C.c_int32), ("cFi", C.c_int32), ("cTi", C.c_int32), ("cCi", C.c_int32),
         ("cFo", C.c_int32), ("cTo", C.c_int32), ("cstride", C.c_int32), ("ctrans", C.c_int32),
         ("sh_shift", C.c_int32), ("sh_heads", C.c_int32), ("sh_L", C.c_int32), ("sh_edge", C.c_int32),
+        ("cphase", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

@@ -33,6 +33,8 @@ def _empty(shape, dtype, dev):
 def conv_gemm(x, wp, bias, out, geom, res=None):
     """Implicit-GEMM 3x3 conv: x [B,Fi,Ti,Ci] -> out [B,Fo,To,Co]; wp [Co][9*Ci]."""
     Co = wp.shape[0]
+    if geom["ctrans"] and res is None:
+        return conv_gemm_transposed(x, wp, bias, out, geom)
     M = geom["cB"] * geom["cFo"] * geom["cTo"]
     kw = dict(A=x, B=wp, C=out, M=M, N=Co, K=9 * geom["cCi"], a_ms=0, a_ks=1, b_ks=1, b_ns=wp.shape[1],
               c_ms=Co, c_ns=1, dtype=_dt(x), a_mode=1, **geom)
@@ -41,6 +43,27 @@ def conv_gemm(x, wp, bias, out, geom, res=None):
     if res is not None:
         kw.update(R=res, r_ms=Co, r_ns=1)
     gemm_raw(**kw)
+
+
+def conv_gemm_transposed(x, wp, bias, out, geom):
+    """Transposed 3x3 stride-2 conv (ConvTranspose2d forward / data gradient of the stride-2 conv) as
+    four GEMMs, one per output parity (fo%2, to%2): each touches only the taps that can reach such
+    a pixel (1, 2, 2 and 4 of the 9), so no structural zeros are multiplied.  wp [Co][9*Ci]."""
+    Co, Ci = wp.shape[0], geom["cCi"]
+    w4 = wp.view(Co, 3, 3, Ci)
+    for pf in (0, 1):
+        for pt in (0, 1):
+            khs = [0, 2] if pf else [1]
+            kws = [0, 2] if pt else [1]
+            Fp, Tp = (geom["cFo"] - pf + 1) // 2, (geom["cTo"] - pt + 1) // 2
+            if Fp <= 0 or Tp <= 0:
+                continue
+            wq = w4[:, khs][:, :, kws].reshape(Co, -1).contiguous()
+            kw = dict(A=x, B=wq, C=out, M=geom["cB"] * Fp * Tp, N=Co, K=wq.shape[1], a_ms=0, a_ks=1, b_ks=1,
+                      b_ns=wq.shape[1], c_ms=Co, c_ns=1, dtype=_dt(x), a_mode=1, cphase=1 + 2 * pf + pt, **geom)
+            if bias is not None:
+                kw.update(bias=bias, bias_mode=1)
+            gemm_raw(**kw)
 
 
 def conv_wgrad(p_side, q_side, geom, M, N):

@@ -185,6 +185,29 @@ def test_conv_transposed_cropped(dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Fi,Ti,Fo,To", [(9, 7, 18, 14), (9, 7, 17, 13), (5, 4, 9, 8)])
+def test_conv_transposed_by_output_parity(dt, Fi, Ti, Fo, To):
+    """ops.conv_gemm on a transposed geometry runs four parity-phase GEMMs (DttGemm::cphase): against
+    F.conv_transpose2d (decoder up-sampling, even planes) and against the data gradient of the
+    stride-2 conv (encoder down-sampling, odd planes: Fo = 2*Fi - 1)."""
+    from dtt_amd import ops
+    g = torch.Generator().manual_seed(Fi * 100 + Fo)
+    dev = "cuda"
+    Bn, Ci, Co = 2, 16, 24
+    x = _mk((Bn, Ci, Fi, Ti), dt, g)
+    w = _mk((Ci, Co, 3, 3), dt, g) * 0.2                     # ConvTranspose2d layout [Ci, Co, 3, 3]
+    bias = torch.randn(Co, generator=g)
+    full = F.conv_transpose2d(x.double(), w.double(), bias.double(), stride=2, padding=1, output_padding=1)
+    ref = full[:, :, :Fo, :To]                                # odd planes: the last row/column is never produced
+    wp = w.permute(1, 2, 3, 0).reshape(Co, 9 * Ci).contiguous().to(dev)
+    out = torch.full((Bn, Fo, To, Co), float("nan"), dtype=dt, device=dev)
+    geom = dict(cB=Bn, cFi=Fi, cTi=Ti, cCi=Ci, cFo=Fo, cTo=To, cstride=2, ctrans=1)
+    ops.conv_gemm(x.permute(0, 2, 3, 1).contiguous().to(dev), wp, bias.to(dev), out, geom)
+    assert not torch.isnan(out.float()).any()
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gemm_row_shift(dt):
     """dW_hh form: C[m][n] = sum_r dG[r][m] * y[r + shift][n], zero at sequence edges."""
     from dtt_amd._lib import gemm_raw, dtype_code

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DttGemm p) {
 // rows, RCS: RC with the LSTM row shift), every chunk 16-byte aligned (checked on the host), per-
 // thread source pointers computed once and advanced by a constant per K-tile.  BK = 64 (bf16) so
 // that k-contiguous rows are read 128 bytes at a time.
-enum { OP_KC = 0, OP_RC = 1, OP_RCS = 2 };
+enum { OP_KC = 0, OP_RC = 1, OP_RCS = 2, OP_CONV = 3 };     // OP_CONV: A rows = output pixels of a 3x3 conv (gather)
 
 template <typename T, int KIND, int ROWS, int BK>
 struct FastLoader {
@@ -480,13 +480,15 @@ struct FastLoader {
     Vec16<T> regs[NIT];
     int nv[NIT];            // KC with K not a multiple of the chunk: valid elements of the chunk just loaded
     bool ragged;
+    int pfo[NIT], pto[NIT]; // OP_CONV: output pixel of the chunk's row
+    static constexpr bool KCL = KIND == OP_KC || KIND == OP_CONV;      // k-contiguous LDS image
 
     __device__ __forceinline__ void init(const T* base, int64_t rs, int64_t ks, int r0, int rmax, int kbeg, int64_t shift) {
         safe = base;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = threadIdx.x + it * 256;
-            if (KIND == OP_KC) {
+            if (KCL) {
                 const int row = idx / (BK / EPT), ch = idx % (BK / EPT);
                 rok[it] = r0 + row < rmax;
                 kofs[it] = ch * EPT;
@@ -498,11 +500,61 @@ struct FastLoader {
                 src[it] = base + ((int64_t)(kbeg + kl) + shift) * ks + (rok[it] ? r0 + rc * EPT : 0);
             }
         }
-        step = KIND == OP_KC ? BK : (int64_t)BK * ks;
+        step = KCL ? BK : (int64_t)BK * ks;
         ragged = false;
+    }
+    // OP_CONV: decode each chunk's output pixel once; src[] = base of its batch item
+    __device__ __forceinline__ void init_conv(const DttGemm& p, const T* base, int r0, int rmax) {
+        safe = base;
+        ragged = false;
+        step = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int row = idx / (BK / EPT), ch = idx % (BK / EPT);
+            rok[it] = r0 + row < rmax;
+            kofs[it] = ch * EPT;
+            int pix = rok[it] ? r0 + row : 0, b;
+            if (p.cphase) {
+                int pf, pt, Fp, Tp;
+                phase_dims(p, pf, pt, Fp, Tp);
+                b = pix / (Fp * Tp); pix -= b * Fp * Tp;
+                const int i = pix / Tp;
+                pfo[it] = 2 * i + pf; pto[it] = 2 * (pix - i * Tp) + pt;
+            } else {
+                b = pix / (p.cFo * p.cTo); pix -= b * p.cFo * p.cTo;
+                pfo[it] = pix / p.cTo; pto[it] = pix - pfo[it] * p.cTo;
+            }
+            src[it] = base + (int64_t)b * p.cFi * p.cTi * p.cCi;
+            nv[it] = EPT;
+        }
+    }
+    __device__ __forceinline__ void load_conv(const DttGemm& p, int k0, int kmax) {
+        int pf = 0, pt = 0;
+        if (p.cphase) { pf = (p.cphase - 1) >> 1; pt = (p.cphase - 1) & 1; }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int gk = k0 + kofs[it];
+            bool ok = rok[it] && gk < kmax;
+            const int tap = gk / p.cCi, ci = gk - tap * p.cCi;
+            int kh, kw;
+            if (p.cphase) { const int nkw = pt ? 2 : 1, ih = tap / nkw; kh = pf ? 2 * ih : 1; kw = pt ? 2 * (tap - ih * nkw) : 1; }
+            else { kh = tap / 3; kw = tap - kh * 3; }
+            int fi, ti;
+            if (!p.ctrans) {
+                fi = pfo[it] * p.cstride + kh - 1; ti = pto[it] * p.cstride + kw - 1;
+                ok = ok && fi >= 0 && fi < p.cFi && ti >= 0 && ti < p.cTi;
+            } else {
+                const int a = pfo[it] + 1 - kh, bb = pto[it] + 1 - kw;
+                fi = a >> 1; ti = bb >> 1;
+                ok = ok && a >= 0 && bb >= 0 && !(a & 1) && !(bb & 1) && fi < p.cFi && ti < p.cTi;
+            }
+            regs[it] = ld16_pred<T>(src[it] + ((int64_t)fi * p.cTi + ti) * p.cCi + ci, safe, ok);
+        }
     }
     // k0: global k of the tile start; kmax: exclusive k bound
     __device__ __forceinline__ void load(const DttGemm& p, int k0, int kmax) {
+        if constexpr (KIND == OP_CONV) { load_conv(p, k0, kmax); return; }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int gk = k0 + kofs[it];
@@ -517,7 +569,7 @@ struct FastLoader {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = threadIdx.x + it * 256;
-            if (KIND == OP_KC) {
+            if (KCL) {
                 const int row = idx / (BK / EPT), ch = idx % (BK / EPT);
                 if (ragged && nv[it] < EPT) {               // zero what lies beyond K (padding may hold anything)
 #pragma unroll
@@ -536,10 +588,10 @@ struct FastLoader {
             }
         }
     }
-    static constexpr int SIZE = (KIND == OP_KC || sizeof(T) == 4) ? ROWS * LD : BK * LDR;
+    static constexpr int SIZE = (KCL || sizeof(T) == 4) ? ROWS * LD : BK * LDR;
     // MFMA fragment of the 32-row block rb at k offset kk (a multiple of 16) of the tile
     static __device__ __forceinline__ typename MM<T>::Frag frag(const T* lds, int rb, int kk, int lane) {
-        if constexpr (sizeof(T) == 2 && KIND != OP_KC) {
+        if constexpr (sizeof(T) == 2 && !KCL) {
             const bf16* r0 = reinterpret_cast<const bf16*>(lds) + (kk + 8 * (lane >> 5) + ((lane & 15) >> 2)) * LDR + rb * 32 +
                              16 * ((lane >> 4) & 1) + 4 * (lane & 3);
             return tr_frag(r0, r0 + 4 * LDR);
@@ -593,7 +645,8 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const DttGemm p) {
 
     LA la;
     LB lb;
-    la.init(reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.a_bs, p.a_ms, p.a_ks, m0, p.M, kt0 * BK, 0);
+    if constexpr (AK == OP_CONV) la.init_conv(p, reinterpret_cast<const T*>(p.A), m0, p.M);
+    else la.init(reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.a_bs, p.a_ms, p.a_ks, m0, p.M, kt0 * BK, 0);
     lb.init(reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.b_bs, p.b_ns, p.b_ks, n0, p.N, kt0 * BK,
             BKD == OP_RCS ? p.sh_shift : 0);
     la.ragged = lb.ragged = (p.K % MM<T>::EPT) != 0;
@@ -644,6 +697,14 @@ template <typename T, int AK, int BKD> int dispatch_fast_tile(const DttGemm& p, 
 // returns 1 if the problem does not qualify for the fast path
 template <typename T> int dispatch_fast(const DttGemm& p, hipStream_t st) {
     constexpr int E = MM<T>::EPT;
+    if (p.a_mode == 1) {
+        // implicit-GEMM conv rows (stride-2 / transposed convs): weights k-contiguous
+        if (p.b_mode != 0 || p.batch != 1 || p.b_ks != 1 || p.b_ns % E != 0 || p.cCi % E != 0 || p.c_ns != 1 ||
+            (p.R && p.r_ns != 1) || (p.atomic && p.bias_mode) || (p.R && p.cphase))
+            return 1;
+        if ((reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.B) & 15)) return 1;
+        return dispatch_fast_tile<T, OP_CONV, OP_KC>(p, st);
+    }
     if (p.a_mode != 0 || (p.b_mode != 0 && p.b_mode != 2)) return 1;
     if (p.c_ns != 1 || (p.R && p.r_ns != 1) || (p.atomic && p.bias_mode)) return 1;
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };

@@ -33,7 +33,9 @@ def _empty(shape, dtype, dev):
 def conv_gemm(x, wp, bias, out, geom, res=None):
     """Implicit-GEMM 3x3 conv: x [B,Fi,Ti,Ci] -> out [B,Fo,To,Co]; wp [Co][9*Ci]."""
     Co = wp.shape[0]
-    if geom["ctrans"] and res is None:
+    if geom["ctrans"] and res is None and Co <= 32:
+        # measured: the four parity GEMMs win only while the tile is narrow (Co = 32: 499 vs 542 us at
+        # full resolution); at Co >= 64 the K of a phase is too short and one 9-tap GEMM is faster
         return conv_gemm_transposed(x, wp, bias, out, geom)
     M = geom["cB"] * geom["cFo"] * geom["cTo"]
     kw = dict(A=x, B=wp, C=out, M=M, N=Co, K=9 * geom["cCi"], a_ms=0, a_ks=1, b_ks=1, b_ns=wp.shape[1],

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DttGemm p) {
 // rows, RCS: RC with the LSTM row shift), every chunk 16-byte aligned (checked on the host), per-
 // thread source pointers computed once and advanced by a constant per K-tile.  BK = 64 (bf16) so
 // that k-contiguous rows are read 128 bytes at a time.
-enum { OP_KC = 0, OP_RC = 1, OP_RCS = 2, OP_CONV = 3 };     // OP_CONV: A rows = output pixels of a 3x3 conv (gather)
+enum { OP_KC = 0, OP_RC = 1, OP_RCS = 2, OP_CONV = 3, OP_WG = 4 };   // OP_WG: B rows gathered at conv tap (wgrad)     // OP_CONV: A rows = output pixels of a 3x3 conv (gather)
 
 template <typename T, int KIND, int ROWS, int BK>
 struct FastLoader {
@@ -529,6 +529,33 @@ struct FastLoader {
             nv[it] = EPT;
         }
     }
+    // OP_WG: k = output pixel of the conv, rows = input channels of the pixel that tap `wtap` reads
+    int wtap, wrow[NIT];
+    __device__ __forceinline__ void init_wg(const T* base, int r0, int rmax, int tap) {
+        safe = base; ragged = false; step = 0; wtap = tap;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int kl = idx / (ROWS / EPT), rc = idx % (ROWS / EPT);
+            rok[it] = r0 + rc * EPT < rmax;
+            kofs[it] = kl;
+            wrow[it] = rok[it] ? r0 + rc * EPT : 0;
+            src[it] = base;
+        }
+    }
+    __device__ __forceinline__ void load_wg(const DttGemm& p, int k0, int kmax) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int gk = k0 + kofs[it];
+            bool ok = rok[it] && gk < kmax;
+            int pix = ok ? gk : 0;
+            const int b = pix / (p.cFo * p.cTo); pix -= b * p.cFo * p.cTo;
+            const int fo = pix / p.cTo, to = pix - fo * p.cTo;
+            int fi, ti;
+            ok = conv_src(p, fo, to, wtap, fi, ti) && ok;
+            regs[it] = ld16_pred<T>(src[it] + ((int64_t)(b * p.cFi + fi) * p.cTi + ti) * p.cCi + wrow[it], safe, ok);
+        }
+    }
     __device__ __forceinline__ void load_conv(const DttGemm& p, int k0, int kmax) {
         int pf = 0, pt = 0;
         if (p.cphase) { pf = (p.cphase - 1) >> 1; pt = (p.cphase - 1) & 1; }
@@ -555,6 +582,7 @@ struct FastLoader {
     // k0: global k of the tile start; kmax: exclusive k bound
     __device__ __forceinline__ void load(const DttGemm& p, int k0, int kmax) {
         if constexpr (KIND == OP_CONV) { load_conv(p, k0, kmax); return; }
+        if constexpr (KIND == OP_WG) { load_wg(p, k0, kmax); return; }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int gk = k0 + kofs[it];
@@ -647,8 +675,9 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const DttGemm p) {
     LB lb;
     if constexpr (AK == OP_CONV) la.init_conv(p, reinterpret_cast<const T*>(p.A), m0, p.M);
     else la.init(reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.a_bs, p.a_ms, p.a_ks, m0, p.M, kt0 * BK, 0);
-    lb.init(reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.b_bs, p.b_ns, p.b_ks, n0, p.N, kt0 * BK,
-            BKD == OP_RCS ? p.sh_shift : 0);
+    if constexpr (BKD == OP_WG) lb.init_wg(reinterpret_cast<const T*>(p.B), n0, p.N, bz);
+    else lb.init(reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.b_bs, p.b_ns, p.b_ks, n0, p.N, kt0 * BK,
+                 BKD == OP_RCS ? p.sh_shift : 0);
     la.ragged = lb.ragged = (p.K % MM<T>::EPT) != 0;
     la.load(p, kt0 * BK, p.K);
     lb.load(p, kt0 * BK, p.K);
@@ -704,6 +733,14 @@ template <typename T> int dispatch_fast(const DttGemm& p, hipStream_t st) {
             return 1;
         if ((reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.B) & 15)) return 1;
         return dispatch_fast_tile<T, OP_CONV, OP_KC>(p, st);
+    }
+    if (p.a_mode == 0 && p.b_mode == 1) {
+        // conv weight gradient: A = dy (or x) [pixel][M] row-contiguous, B gathered at the tap = batch index
+        if (!(p.a_ms == 1 && p.a_ks % E == 0 && (p.M % E == 0 || p.a_ks >= (p.M + E - 1) / E * E) && p.a_bs == 0 &&
+              p.cCi % E == 0 && p.N % E == 0 && p.c_ns == 1 && p.atomic && !p.bias_mode))
+            return 1;
+        if ((reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.B) & 15)) return 1;
+        return dispatch_fast_tile<T, OP_RC, OP_WG>(p, st);
     }
     if (p.a_mode != 0 || (p.b_mode != 0 && p.b_mode != 2)) return 1;
     if (p.c_ns != 1 || (p.R && p.r_ns != 1) || (p.atomic && p.bias_mode)) return 1;

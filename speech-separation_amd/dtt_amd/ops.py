@@ -73,7 +73,7 @@ def conv_wgrad(p_side, q_side, geom, M, N):
     P = geom["cB"] * geom["cFo"] * geom["cTo"]
     dwp = torch.zeros(M, 9, N, dtype=F32, device=p_side.device)
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * 9
-    splitk = max(1, min(512, (2048 + tiles - 1) // tiles, (P + 255) // 256))
+    splitk = int(max(1, min(512, round(768 / tiles), (P + 255) // 256)))     # ~3 workgroups per CU: atomic tail
     gemm_raw(A=p_side, B=q_side, C=dwp, M=M, N=N, K=P, batch=9, splitk=splitk, a_ms=1, a_ks=M, a_bs=0,
              b_ks=N, b_ns=1, b_bs=0, c_ms=9 * N, c_ns=1, c_bs=N, dtype=_dt(p_side), atomic=1, out_f32=1,
              b_mode=1, **geom)

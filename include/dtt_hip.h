@@ -109,6 +109,12 @@ int dtt_gn_bwd(const void* x, const void* dxn, const void* dres, const float* ga
 /* Deterministic column sums (bias gradients): out[nchunks][W]. */
 int dtt_colsum(const void* in, float* out, int64_t R, int W, int64_t ld, int nchunks, int dtype, void* stream);
 
+/* Weighted column sums out[chunk][m][w] = sum_r a[r][m] * in[r][w] (m < MW <= 8): weight gradient of a
+ * 1x1 conv with a handful of outputs -- the mask head decoder.out_conv (decoder.py:29), dW = dmask^T x.
+ * Finish with dtt_colsum over the chunks (width MW*W). */
+int dtt_wcolsum(const void* a, const void* in, float* out, int64_t R, int W, int MW, int nchunks, int dtype,
+                void* stream);
+
 /* Fused BiLSTM forward for bf16, H = 256, C' = 128 (the bench configuration): the input projection
  * x*W_ih^T + b_ih + b_hh of nn.LSTM (reference src/model/DTTNet/modules/latent.py:87-92) is computed
  * inside the recurrent kernel, so no [rows][2][4H] pre-activation tensor exists.

@@ -139,27 +139,43 @@ __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.f;
 
-    const int nchunks = (p.Ci + KC - 1) / KC;
-    for (int c = 0; c < nchunks; ++c) {
+    // 32-channel chunks of Ci; the next chunk's patch and weights are fetched into registers while
+    // the current one is in the MFMAs (16-byte pieces: NP of the patch, NW of the weights per thread)
+    constexpr int NPC = PH * PW * CPR, NP = (NPC + 255) / 256, NWC = 9 * BN * CPR, NW = (NWC + 255) / 256;
+    Vec16<T> pre_p[NP], pre_w[NW];
+    auto fetch = [&](int c) {
         const int ci0 = c * KC;
-        if (c) __syncthreads();
-        // ---- stage the input patch (zero outside the image / beyond Ci)
-        for (int idx = tid; idx < PH * PW * CPR; idx += 256) {
-            int pp = idx / CPR, ch = idx % CPR;
-            int pf = pp / PW, pt = pp - pf * PW;
-            int f = f0 - 1 + pf, t = t0 - 1 + pt, ci = ci0 + ch * EPT;
-            Vec16<T> v = ld16_pred<T>(x + ((int64_t)f * p.T + t) * p.Ci + ci, x,
-                                      f >= 0 && f < p.F && t >= 0 && t < p.T && ci < p.Ci);
-            st16<T>(patch + pp * LDC + ch * EPT, v);
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int idx = tid + it * 256, pp = idx / CPR, ch = idx % CPR;
+            const int pf = pp / PW, pt = pp - pf * PW;
+            const int f = f0 - 1 + pf, t = t0 - 1 + pt, ci = ci0 + ch * EPT;
+            pre_p[it] = ld16_pred<T>(x + ((int64_t)f * p.T + t) * p.Ci + ci, x,
+                                     idx < NPC && f >= 0 && f < p.F && t >= 0 && t < p.T && ci < p.Ci);
         }
-        // ---- stage the weights of this channel chunk: wl[tap][col][ci]
-        for (int idx = tid; idx < 9 * BN * CPR; idx += 256) {
-            int row = idx / CPR, ch = idx % CPR;
-            int tap = row / BN, col = row - tap * BN, ci = ci0 + ch * EPT;
-            Vec16<T> v = ld16_pred<T>(wp + ((int64_t)(co0 + col) * 9 + tap) * p.Ci + ci, wp, ci < p.Ci);
-            st16<T>(wl + row * LDC + ch * EPT, v);
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            const int idx = tid + it * 256, row = idx / CPR, ch = idx % CPR;
+            const int tap = row / BN, col = row - tap * BN, ci = ci0 + ch * EPT;
+            pre_w[it] = ld16_pred<T>(wp + ((int64_t)(co0 + col) * 9 + tap) * p.Ci + ci, wp, idx < NWC && ci < p.Ci);
+        }
+    };
+    const int nchunks = (p.Ci + KC - 1) / KC;
+    fetch(0);
+    for (int c = 0; c < nchunks; ++c) {
+        if (c) __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < NPC) st16<T>(patch + (idx / CPR) * LDC + (idx % CPR) * EPT, pre_p[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < NWC) st16<T>(wl + (idx / CPR) * LDC + (idx % CPR) * EPT, pre_w[it]);
         }
         __syncthreads();
+        if (c + 1 < nchunks) fetch(c + 1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kh = tap / 3, kw = tap % 3;

@@ -449,6 +449,59 @@ __global__ __launch_bounds__(NT) void colsum_vec_kernel(const T* __restrict__ in
     }
 }
 
+// Weighted column sums: out[chunk][m][w] = sum_r a[r][m] * in[r][w], m < MW <= 8 (the weight gradient
+// of a 1x1 conv with a handful of outputs, e.g. the mask head: dW[2S][C] = dmask^T x).  Same thread
+// layout as colsum_vec_kernel: HBM-bound, one pass over `in`.
+template <typename T>
+__global__ __launch_bounds__(NT) void wcolsum_kernel(const T* __restrict__ a, const T* __restrict__ in,
+                                                     float* __restrict__ out, int64_t R, int W, int MW,
+                                                     int64_t rows_per, int CWb) {
+    constexpr int E = Vec16<T>::N;
+    __shared__ float red[NT * E];
+    const int RL = NT / CWb;
+    const int cl = threadIdx.x % CWb, rl = threadIdx.x / CWb;
+    const int chunk = blockIdx.x * CWb + cl;
+    const bool okc = chunk * E < W && rl < RL;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    float s[8][E];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[m][e] = 0.f;
+    const T* base = in + (okc ? (int64_t)chunk * E : 0);
+    for (int64_t r = r0 + rl; r < r1; r += 2 * RL) {
+        Vec16<T> v[2];
+        float av[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t rr = r + (int64_t)u * RL;
+            const bool ok = okc && rr < r1;
+            v[u] = ld16_pred<T>(base + rr * W, base, ok);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) av[u][m] = (ok && m < MW) ? ldf(a + (ok ? rr : r0) * MW + (m < MW ? m : 0)) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int e = 0; e < E; ++e) s[m][e] += av[u][m] * v[u].get(e);
+    }
+    for (int m = 0; m < MW; ++m) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) red[threadIdx.x * E + e] = s[m][e];
+        __syncthreads();
+        for (int c = threadIdx.x; c < CWb * E; c += NT) {
+            const int gw = blockIdx.x * CWb * E + c;
+            if (gw >= W) continue;
+            float acc = 0.f;
+            for (int q = 0; q < RL; ++q) acc += red[(q * CWb + c / E) * E + (c % E)];
+            out[((int64_t)blockIdx.y * MW + m) * W + gw] = acc;
+        }
+    }
+}
+
 int ept_of(int dtype) { return dtype ? 8 : 4; }
 
 // pixels per workgroup for the elementwise IN kernels: >= 8 unrolled sweeps of the block, ~16 workgroups per CU
@@ -561,3 +614,22 @@ extern "C" int dtt_colsum(const void* in, float* out, int64_t R, int W, int64_t 
     DTT_LAUNCH_CHECK();
     return 0;
 }
+
+// out[nchunks][MW][W] = per-chunk partial sums of a[r][m] * in[r][w]; finish with dtt_colsum over the
+// chunks (W' = MW*W).  a [R][MW], in [R][W] (ld = W), same dtype; W a multiple of the 16-byte chunk.
+extern "C" int dtt_wcolsum(const void* a, const void* in, float* out, int64_t R, int W, int MW, int nchunks, int dtype,
+                           void* stream) {
+    const int E = ept_of(dtype);
+    DTT_CHECK(R > 0 && W > 0 && MW > 0 && MW <= 8 && nchunks > 0 && nchunks <= 65535 && W % E == 0,
+              "dtt_wcolsum: bad shape W=%d MW=%d", W, MW);
+    DTT_CHECK((reinterpret_cast<uintptr_t>(in) & 15) == 0, "dtt_wcolsum: unaligned input");
+    const int64_t per = (R + nchunks - 1) / nchunks;
+    int cw = W / E, CWb = 1;
+    while (CWb < cw && CWb < NT) CWb <<= 1;
+    dim3 grid((cw + CWb - 1) / CWb, nchunks);
+    if (dtype) hipLaunchKernelGGL(wcolsum_kernel<bf16>, grid, dim3(NT), 0, ST, (const bf16*)a, (const bf16*)in, out, R, W, MW, per, CWb);
+    else hipLaunchKernelGGL(wcolsum_kernel<float>, grid, dim3(NT), 0, ST, (const float*)a, (const float*)in, out, R, W, MW, per, CWb);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+

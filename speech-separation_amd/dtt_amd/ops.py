@@ -651,9 +651,16 @@ class MaskISTFT(torch.autograd.Function):
                                  ptr(dspec.contiguous().float()), ptr(dphase.contiguous().float()), ptr(dZ), ptr(dx),
                                  ptr(dmask), B, Fq, T, Cc, S, ld, imoff, d, stream_ptr()), "dtt_mask_bwd")
         P = B * Fq * T
-        dw = torch.zeros(2 * S, Cc, dtype=F32, device=dev)
-        gemm_raw(A=dmask, B=x, C=dw, M=2 * S, N=Cc, K=P, splitk=_splitk(2 * S, Cc, P), a_ms=1, a_ks=2 * S,
-                 b_ks=Cc, b_ns=1, c_ms=Cc, c_ns=1, dtype=d, atomic=1, out_f32=1)
+        if 2 * S <= 8 and Cc % (8 if dt == torch.bfloat16 else 4) == 0:
+            nch = int(max(1, min(1024, P // 512)))
+            part = _empty((nch, 2 * S * Cc), F32, dev)
+            check(lib().dtt_wcolsum(ptr(dmask), ptr(x), ptr(part), C.c_int64(P), Cc, 2 * S, nch, d, stream_ptr()),
+                  "dtt_wcolsum")
+            dw = colsum(part, nch, 2 * S * Cc).view(2 * S, Cc)
+        else:
+            dw = torch.zeros(2 * S, Cc, dtype=F32, device=dev)
+            gemm_raw(A=dmask, B=x, C=dw, M=2 * S, N=Cc, K=P, splitk=_splitk(2 * S, Cc, P), a_ms=1, a_ks=2 * S,
+                     b_ks=Cc, b_ns=1, c_ms=Cc, c_ns=1, dtype=d, atomic=1, out_f32=1)
         db = colsum(dmask, P, 2 * S)
         return dx, dw.view(wshape), db, None, None, None, None, None, None
 

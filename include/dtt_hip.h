@@ -71,7 +71,7 @@ int dtt_gemm(const DttGemm* p, void* stream);
 
 /* Dedicated 3x3 stride-1 'same' conv on channels-last (block_tfc_tdf.py:12-32): LDS input
  * patches shared by the nine taps; wp = [Co][9][Ci]; optional fused residual and fused
- * InstanceNorm statistics (partial scratch [B][4*ceil(F/16)][ceil(T/16)][Co][2] -> stats
+ * InstanceNorm statistics (partial scratch of B*(4*ceil(F/16)*ceil(T/16)+4)*Co*3 floats (layout private to the kernels) -> stats
  * [B][Co][2] = {mean, rstd}).  The same kernel computes the data gradient (flipped weights).
  * dtt_conv3x3_wgrad: dw[Co][9][Ci] fp32 += sum_px dy[px][co] x[px+tap][ci] (bf16 operands,
  * transposing LDS reads; caller zeroes dw). */

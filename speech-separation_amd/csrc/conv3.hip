@@ -25,9 +25,13 @@ struct Conv3P {
 // (+bias) are parked in a wave-private fp32 LDS slab and leave as 16-byte chunks -- a tile row of 16
 // pixels is one contiguous run of 16*Co elements in the channels-last tensor -- with the residual
 // read the same way.  Also the per-tile InstanceNorm statistics {mean, M2}; all four waves must call.
+// Per-lane running InstanceNorm sums of a persistent workgroup (conv3x3_c32_kernel): accumulated over
+// all tiles of one batch item about a fixed pivot, flushed once per (workgroup, wave, batch item).
+struct RunStat { float piv, s1, s2, n; bool open; };
+
 template <typename T, int TN>
 __device__ __forceinline__ void conv3_epilogue(const Conv3P& p, f32x16_t (&acc)[2][TN], float* stage,
-                                               int b, int tf, int tt, int co0) {
+                                               int b, int tf, int tt, int co0, RunStat* run = nullptr) {
     constexpr int BN = 32 * TN, SW = BN + 4, E = Vec16<T>::N, CPP = BN / E, NIT = CPP;   // 64 px * CPP chunks / 64 lanes
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int f0 = tf * TH, t0 = tt * TW;
@@ -42,6 +46,10 @@ __device__ __forceinline__ void conv3_epilogue(const Conv3P& p, f32x16_t (&acc)[
         bsv[j] = bp[p.bias ? co0 + j * 32 + lr : 0];
         s1[j] = 0.f; s2[j] = 0.f;
         piv[j] = __shfl(acc[0][j][0] + bsv[j], lr, 64);
+    }
+    if (run) {                                             // TN == 1: keep the pivot of the run
+        if (!run->open) { run->piv = piv[0]; run->s1 = 0.f; run->s2 = 0.f; run->n = 0.f; run->open = true; }
+        piv[0] = run->piv;
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -100,6 +108,7 @@ __device__ __forceinline__ void conv3_epilogue(const Conv3P& p, f32x16_t (&acc)[
     // fp32 sum and sum of squares over <= 64 pixels; the slabs are merged (Chan) by conv_stats_finalize.
     const int nr = min(4, max(0, p.F - (f0 + wave * 4))), ntv = min(TW, p.T - t0);
     const float n = (float)(nr * ntv), inv_n = n > 0.f ? 1.f / n : 0.f;
+    if (run) { run->s1 += s1[0]; run->s2 += s2[0]; run->n += n; return; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
@@ -234,8 +243,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles
         }
     };
     prefetch(tile0);
+    // InstanceNorm partials: one {mean, M2, n} per (batch item, workgroup slot, wave, channel), the slot
+    // being the workgroup's index among those that touch the batch item (see conv_c32_stats_finalize)
+    RunStat run{0.f, 0.f, 0.f, 0.f, false};
+    int run_b = -1;
+    const int nslot = (per_b + tiles_per_wg - 1) / tiles_per_wg + 1;
+    auto flush = [&]() {
+        if (!run.open || !p.partial) return;
+        const float a1 = run.s1 + __shfl_xor(run.s1, 32, 64), a2 = run.s2 + __shfl_xor(run.s2, 32, 64);
+        if (lh == 0) {
+            const float dm = run.n > 0.f ? a1 / run.n : 0.f;
+            const int slot = blockIdx.x - (run_b * per_b) / tiles_per_wg;
+            float* d = p.partial + ((((int64_t)run_b * nslot + slot) * 4 + wave) * 32 + lr) * 3;
+            d[0] = run.piv + dm; d[1] = fmaxf(a2 - a1 * dm, 0.f); d[2] = run.n;
+        }
+        run.open = false;
+    };
     for (int tile = tile0; tile < tile1; ++tile) {
         const int b = tile / per_b, rr = tile - b * per_b, tf = rr / p.tiles_t, tt = rr - tf * p.tiles_t;
+        if (b != run_b) { flush(); run_b = b; }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256;
@@ -261,8 +287,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles
                 }
             }
         }
-        conv3_epilogue<bf16, 1>(p, acc, stage_all + wave * 64 * SW, b, tf, tt, 0);
+        conv3_epilogue<bf16, 1>(p, acc, stage_all + wave * 64 * SW, b, tf, tt, 0, p.partial ? &run : nullptr);
         __syncthreads();                                    // patch is free for the next tile
+    }
+    flush();
+}
+
+// stats[b][c] = {mean, rstd} from the per-(workgroup, wave) partials of conv3x3_c32_kernel: a few dozen
+// {mean, M2, n} triples per channel, merged in two plain passes by one thread per channel.
+__global__ __launch_bounds__(1024) void conv_c32_stats_finalize(const float* __restrict__ partial, float* __restrict__ stats,
+                                                                int per_b, int tiles_per_wg, int total, float ntot, float eps) {
+    __shared__ float sh[32][33];
+    __shared__ float gmean[32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5, b = blockIdx.x;
+    const int nslot = (per_b + tiles_per_wg - 1) / tiles_per_wg + 1;
+    const int wg0 = (b * per_b) / tiles_per_wg, wg1 = min(((b + 1) * per_b - 1) / tiles_per_wg, (total - 1) / tiles_per_wg);
+    const int nitem = (wg1 - wg0 + 1) * 4;                 // (slot, wave) pairs, contiguous in the buffer
+    const float* base = partial + (int64_t)b * nslot * 4 * 32 * 3 + c * 3;
+    float acc = 0.f;
+    for (int i = g; i < nitem; i += 32) { const float* d = base + i * 32 * 3; acc += d[2] * d[0]; }
+    sh[g][c] = acc;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.f;
+        for (int q = 0; q < 32; ++q) t += sh[q][c];
+        gmean[c] = t / ntot;
+    }
+    __syncthreads();
+    const float mean = gmean[c];
+    acc = 0.f;
+    for (int i = g; i < nitem; i += 32) {
+        const float* d = base + i * 32 * 3;
+        const float dd = d[0] - mean;
+        acc += d[2] > 0.f ? d[1] + d[2] * dd * dd : 0.f;
+    }
+    sh[g][c] = acc;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.f;
+        for (int q = 0; q < 32; ++q) t += sh[q][c];
+        stats[((int64_t)b * 32 + c) * 2] = mean;
+        stats[((int64_t)b * 32 + c) * 2 + 1] = rsqrtf(t / ntot + eps);
     }
 }
 
@@ -438,7 +503,7 @@ __global__ __launch_bounds__(256, CT == 32 ? 2 : 1) void conv3x3_wgrad_kernel(Wg
 #define ST reinterpret_cast<hipStream_t>(stream)
 
 // y = conv3x3_same(x, wp [Co][9][Ci]) + bias (+ res); if partial != NULL also the InstanceNorm
-// statistics: partial scratch [B][4*tiles_f][tiles_t][Co][2], stats [B][Co][2] = {mean, rstd}.
+// statistics: partial scratch of B*(4*tiles_f*tiles_t+4)*Co*3 floats, stats [B][Co][2] = {mean, rstd}.
 extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, void* y, const void* res,
                               float* partial, float* stats, int B, int F, int T, int Ci, int Co, float eps, int dtype,
                               void* stream) {
@@ -447,11 +512,11 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
     Conv3P p{x, wp, bias, y, res, partial, B, F, T, Ci, Co, (F + TH - 1) / TH, (T + TW - 1) / TW};
     if (dtype == 1 && Ci == 32 && Co == 32) {
         const int total = B * p.tiles_f * p.tiles_t;
-        const int tpw = max(1, min(16, total / 1024));       // ~4 workgroups per CU at full size
+        const int tpw = max(1, (total + 511) / 512);         // ONE resident wave of workgroups: 2 per CU x 256 CUs
         hipLaunchKernelGGL(conv3x3_c32_kernel, dim3((total + tpw - 1) / tpw), dim3(256), 0, ST, p, tpw);
         if (partial)
-            hipLaunchKernelGGL(conv_stats_finalize, dim3((Co + 31) / 32, B), dim3(1024), 0, ST, partial, stats, F, T, Co,
-                               p.tiles_f, p.tiles_t, eps);
+            hipLaunchKernelGGL(conv_c32_stats_finalize, dim3(B), dim3(1024), 0, ST, partial, stats, p.tiles_f * p.tiles_t,
+                               tpw, total, (float)F * (float)T, eps);
         DTT_LAUNCH_CHECK();
         return 0;
     }

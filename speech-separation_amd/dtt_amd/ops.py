@@ -153,7 +153,7 @@ def conv3x3_s1(x, wp, bias, res=None, want_stats=False, eps=1e-5):
     y = _empty((B, Fq, T, Co), x.dtype, x.device)
     part = stats = None
     if want_stats:
-        part = _empty((B, 4 * ((Fq + 15) // 16), (T + 15) // 16, Co, 2), F32, x.device)
+        part = _empty((B, 4 * ((Fq + 15) // 16) * ((T + 15) // 16) + 4, Co, 3), F32, x.device)
         stats = _empty((B, Co, 2), F32, x.device)
     check(lib().dtt_conv3x3_s1(ptr(x), ptr(wp), ptr(bias), ptr(y), ptr(res), ptr(part), ptr(stats), B, Fq, T, Ci, Co,
                                C.c_float(eps), _dt(x), stream_ptr()), "dtt_conv3x3_s1")

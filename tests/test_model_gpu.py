@@ -156,6 +156,31 @@ def test_idp_module_h256_bf16_vs_oracle(B, Fq, T):
         assert grad_close(p_.grad, sdr[k].grad, 4e-2, atol=1e-2 * float(sdr[k].grad.abs().max()) + 1e-6), k
 
 
+@pytest.mark.parametrize("Cc,dt,tol", [(512, torch.float32, 5e-5), (512, torch.bfloat16, 4e-2), (1024, torch.bfloat16, 4e-2)])
+def test_idp_module_wide_hidden_vs_oracle(Cc, dt, tol):
+    """Wider latent widths (cfg5: g = 64 -> C' = 512, H = 1024) run the general recurrent kernels
+    (hidden columns in sequential passes): forward + all gradients against the CPU oracle."""
+    from dtt_amd.model import IDPModule
+    heads, B, Fq, T = 2, 1, 4, 5
+    m = IDPModule(heads, Cc).to(DEV)
+    sd = fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 11)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(Cc)
+    x = torch.randn(B, Cc, Fq, T, generator=g)
+    gy = torch.randn(B, Cc, Fq, T, generator=g)
+    xr = x.clone().requires_grad_(True)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yr = oracle.idp(sdr, "", xr, heads)
+    yr.backward(gy)
+    xd = _nhwc(x, dt).requires_grad_(True)
+    y = m(xd)
+    assert rel_err(_nchw(y), yr.detach()) < tol
+    y.backward(_nhwc(gy, dt))
+    assert rel_err(_nchw(xd.grad), xr.grad) < 2 * tol
+    for k, p_ in m.named_parameters():
+        assert grad_close(p_.grad, sdr[k].grad, 2 * tol, atol=tol * float(sdr[k].grad.abs().max()) + 1e-6), k
+
+
 def _run_tiny(precision):
     import dtt_amd
     from dtt_amd.model import _Tap

@@ -16,12 +16,18 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
+    """Gradients are produced by autograd as free tensors (``zero_grad`` sets them to None, so the first
+    accumulation is a move, not an add kernel per parameter).  When the last gradient of a bucket has
+    arrived they are gathered into the bucket's flat fp32 buffer by ONE multi-tensor copy, ``p.grad`` is
+    re-pointed at the views, and the bucket's all-reduce is issued asynchronously.  With one process
+    (world size 1) nothing is exchanged and the reducer is a pass-through."""
+
     def __init__(self, module, bucket_bytes=32 << 20, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        params = [p for p in module.parameters() if p.requires_grad]
-        params.reverse()                                  # backward order ~ reverse registration order
-        self.buckets = []                                 # (flat, [params])
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        params = list(reversed(self.params))              # backward order ~ reverse registration order
+        self.buckets = []                                 # (flat, [params], [views])
         cur, cur_n = [], 0
         for p in params:
             cur.append(p)
@@ -33,19 +39,21 @@ class GradBucketReducer:
             self._make_bucket(cur)
         self._pending = []
         self._hooks = []
-        for bi, (_, ps) in enumerate(self.buckets):
-            for p in ps:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
         self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        if self.world > 1:
+            for bi, (_, ps, _) in enumerate(self.buckets):
+                for p in ps:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
     def _make_bucket(self, ps):
         n = sum(p.numel() for p in ps)
         flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
-        off = 0
+        views, off = [], 0
         for p in ps:
-            p.grad = flat[off:off + p.numel()].view_as(p)   # gradients accumulate straight into the bucket
+            views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.buckets.append((flat, list(ps)))
+        self.buckets.append((flat, list(ps), views))
 
     def _make_hook(self, bi):
         def hook(_p):
@@ -55,28 +63,35 @@ class GradBucketReducer:
         return hook
 
     def _launch(self, bi):
-        if self.world > 1:
-            flat = self.buckets[bi][0]
-            self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        flat, ps, views = self.buckets[bi]
+        have = [(v, p.grad) for v, p in zip(views, ps) if p.grad is not None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(views, ps):
+            if p.grad is None:
+                v.zero_()                                 # parameter unused this step: contributes zero
+            p.grad = v
+        self._launched[bi] = True
+        self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def zero_grad(self):
-        """Keep the bucket views (set_to_none would detach them)."""
-        for flat, _ in self.buckets:
-            flat.zero_()
+        for p in self.params:
+            p.grad = None
         self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
 
     def finish(self):
         """Wait for the outstanding all-reduces and turn sums into means."""
-        if self.world > 1:
-            for bi, r in enumerate(self._ready):          # buckets holding parameters that got no gradient
-                if r != len(self.buckets[bi][1]):
-                    self._launch(bi)
+        if self.world == 1:
+            return
+        for bi in range(len(self.buckets)):               # buckets holding parameters that got no gradient
+            if not self._launched[bi]:
+                self._launch(bi)
         for w in self._pending:
             w.wait()
         self._pending = []
-        if self.world > 1:
-            for flat, _ in self.buckets:
-                flat.mul_(1.0 / self.world)
+        for flat, _, _ in self.buckets:
+            flat.mul_(1.0 / self.world)
 
     def remove(self):
         for h in self._hooks:

@@ -27,6 +27,30 @@ def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
+_ZARENA = {}
+
+
+def _zeros_f32(shape, dev):
+    """fp32 zeros carved out of a 64 MiB arena that is zero-filled by ONE kernel: the atomic weight-
+    gradient targets and the identically-zero bias gradients need ~170 zeroed tensors per step, and a
+    fill kernel each costs more than the arithmetic behind many of them.  A chunk is handed out once
+    and never reused (a fresh arena replaces an exhausted one; the old one lives as long as its views)."""
+    if isinstance(shape, int):
+        shape = (shape,)
+    n = 1
+    for s in shape:
+        n *= int(s)
+    need = (n + 63) // 64 * 64                              # 256-byte granules keep every view 16-byte aligned
+    key = (dev.type, dev.index)
+    ar = _ZARENA.get(key)
+    if ar is None or ar[1] + need > ar[0].numel():
+        ar = [torch.zeros(max(16 << 20, need), dtype=F32, device=dev), 0]
+        _ZARENA[key] = ar
+    out = ar[0][ar[1]:ar[1] + n].view(shape)
+    ar[1] += need
+    return out
+
+
 # --------------------------------------------------------------------------- #
 # thin wrappers over the C entry points
 # --------------------------------------------------------------------------- #
@@ -71,7 +95,7 @@ def conv_gemm_transposed(x, wp, bias, out, geom):
 def conv_wgrad(p_side, q_side, geom, M, N):
     """dWp[m][tap][n] = sum_p P[p][m] * Q[src(p,tap)][n]; geom: cFo/cTo = P grid, cFi/cTi = Q grid."""
     P = geom["cB"] * geom["cFo"] * geom["cTo"]
-    dwp = torch.zeros(M, 9, N, dtype=F32, device=p_side.device)
+    dwp = _zeros_f32((M, 9, N,), p_side.device)
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * 9
     splitk = int(max(1, min(512, round(768 / tiles), (P + 255) // 256)))     # ~3 workgroups per CU: atomic tail
     gemm_raw(A=p_side, B=q_side, C=dwp, M=M, N=N, K=P, batch=9, splitk=splitk, a_ms=1, a_ks=M, a_bs=0,
@@ -192,18 +216,26 @@ def _conv_geoms(kind, B, Fi, Ti, Ci, Co):
     return Fo, To, fwd, dgrad, wg
 
 
+def _cast_perm(w, perm, dt):
+    """Permute + dtype cast of a parameter in ONE copy kernel (permute().reshape().to() takes two)."""
+    v = w.permute(*perm)
+    out = torch.empty(v.shape, dtype=dt, device=w.device)
+    out.copy_(v)
+    return out
+
+
 def _pack_fwd(w, kind, dt):
     if kind == "up":      # ConvTranspose2d weight [Ci, Co, 3, 3]
-        return w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()
-    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
+        return _cast_perm(w, (1, 2, 3, 0), dt).view(w.shape[1], -1)
+    return _cast_perm(w, (0, 2, 3, 1), dt).view(w.shape[0], -1)
 
 
 def _pack_dgrad(w, kind, dt):
     if kind == "s1":
-        return w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()
+        return _cast_perm(w.flip(2, 3), (1, 2, 3, 0), dt).view(w.shape[1], -1)
     if kind == "down":
-        return w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()
-    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()      # up: [Ci][tap][Co]
+        return _cast_perm(w, (1, 2, 3, 0), dt).view(w.shape[1], -1)
+    return _cast_perm(w, (0, 2, 3, 1), dt).view(w.shape[0], -1)                    # up: [Ci][tap][Co]
 
 
 def _conv_backward(kind, x, w, dy, need_dx):
@@ -213,7 +245,7 @@ def _conv_backward(kind, x, w, dy, need_dx):
     _, _, _, gd, gw = _conv_geoms(kind, B, Fi, Ti, Ci, Co)
     if kind == "s1" and _fast3(dy, Ci) and _fast3(x, Co):
         if x.dtype == torch.bfloat16:
-            dwp = torch.zeros(Co, 9, Ci, dtype=F32, device=x.device)
+            dwp = _zeros_f32((Co, 9, Ci,), x.device)
             check(lib().dtt_conv3x3_wgrad(ptr(dy), ptr(x), ptr(dwp), B, Fi, Ti, Ci, Co, 1, stream_ptr()),
                   "dtt_conv3x3_wgrad")
         else:
@@ -261,7 +293,7 @@ class ConvNormGelu(torch.autograd.Function):
         dy = in_gelu_bwd(y, dz.contiguous(), stats)
         dx, dw = _conv_backward(ctx.kind, x, w, dy, ctx.needs_input_grad[0])
         # the bias feeds an affine-free InstanceNorm: its gradient is identically zero
-        db = torch.zeros(w.shape[1] if ctx.kind == "up" else w.shape[0], dtype=F32, device=x.device)
+        db = _zeros_f32((w.shape[1] if ctx.kind == "up" else w.shape[0],), x.device)
         return dx, dw, db, None, None
 
 
@@ -330,17 +362,17 @@ class TDF(torch.autograd.Function):
         dx = torch.empty_like(x)
         gemm_raw(A=w1p, B=dhid, C=dx, R=dout, M=Fq, N=N, K=J, batch=B, a_ms=1, a_ks=Fp, a_bs=0, b_ks=N, b_ns=1,
                  b_bs=J * N, c_ms=N, c_ns=1, c_bs=Fq * N, r_ms=N, r_ns=1, r_bs=Fq * N, dtype=d)
-        dw2 = torch.zeros(Fq, J, dtype=F32, device=dev)
+        dw2 = _zeros_f32((Fq, J,), dev)
         gemm_raw(A=dout, B=hid, C=dw2, M=Fq, N=J, K=N, batch=B, splitk=_splitk(Fq, J, N, B), a_ms=N, a_ks=1, a_bs=Fq * N, b_ks=1,
                  b_ns=N, b_bs=J * N, c_ms=J, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
-        dw1 = torch.zeros(J, Fq, dtype=F32, device=dev)
+        dw1 = _zeros_f32((J, Fq,), dev)
         gemm_raw(A=dhid, B=x, C=dw1, M=J, N=Fq, K=N, batch=B, splitk=_splitk(J, Fq, N, B), a_ms=N, a_ks=1, a_bs=J * N, b_ks=1,
                  b_ns=N, b_bs=Fq * N, c_ms=Fq, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
         ones = torch.ones(N, dtype=x.dtype, device=dev)
-        db2 = torch.zeros(Fq, dtype=F32, device=dev)
+        db2 = _zeros_f32((Fq,), dev)
         gemm_raw(A=dout, B=ones, C=db2, M=Fq, N=1, K=N, batch=B, a_ms=N, a_ks=1, a_bs=Fq * N, b_ks=1, b_ns=0,
                  b_bs=0, c_ms=1, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
-        db1 = torch.zeros(J, dtype=F32, device=dev)
+        db1 = _zeros_f32((J,), dev)
         gemm_raw(A=dhid, B=ones, C=db1, M=J, N=1, K=N, batch=B, a_ms=N, a_ks=1, a_bs=J * N, b_ks=1, b_ns=0,
                  b_bs=0, c_ms=1, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
         return dx, dw1, db1, dw2, db2
@@ -352,13 +384,13 @@ class TDF(torch.autograd.Function):
 def _pack_whh_fwd(w, dt):
     """[4H, H] -> MFMA B-fragment order [4H/32][H/16][64 lanes][8]."""
     G4, H = w.shape
-    return w.view(G4 // 32, 32, H // 16, 2, 8).permute(0, 2, 3, 1, 4).to(dt).contiguous()
+    return _cast_perm(w.view(G4 // 32, 32, H // 16, 2, 8), (0, 2, 3, 1, 4), dt)
 
 
 def _pack_whh_bwd(w, dt):
     """[4H, H] -> fragments of B[k][n] = W_hh[k][n] for dh = dG * W_hh: [H/32][4H/16][64][8]."""
     G4, H = w.shape
-    return w.view(G4 // 16, 2, 8, H // 32, 32).permute(3, 0, 1, 4, 2).to(dt).contiguous()
+    return _cast_perm(w.view(G4 // 16, 2, 8, H // 32, 32), (3, 0, 1, 4, 2), dt)
 
 
 def _unblock(t, W, N, L, heads):
@@ -456,7 +488,7 @@ class DualPathRNN(torch.autograd.Function):
         dy = _empty((R, 2 * H), dt, dev)
         gemm_raw(A=dout, B=fcw, C=dy, M=R, N=2 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=2 * H, b_ns=1, c_ms=2 * H, c_ns=1,
                  dtype=d)
-        dfcw = torch.zeros(Cp, 2 * H, dtype=F32, device=dev)
+        dfcw = _zeros_f32((Cp, 2 * H,), dev)
         gemm_raw(A=dout, B=y, C=dfcw, M=Cp, N=2 * H, K=R, splitk=_splitk(Cp, 2 * H, R), a_ms=1, a_ks=Cp, b_ks=2 * H, b_ns=1,
                  c_ms=2 * H, c_ns=1, dtype=d, atomic=1, out_f32=1)
         dfcb = colsum(dout, R, Cp)
@@ -472,12 +504,12 @@ class DualPathRNN(torch.autograd.Function):
         G4 = 4 * H
         dwhh = []
         for di, (shift, edge) in enumerate(((-heads, 0), (heads, L - 1))):
-            g = torch.zeros(G4, H, dtype=F32, device=dev)
+            g = _zeros_f32((G4, H,), dev)
             gemm_raw(A=dG[:, di], B=y[:, di * H:], C=g, M=G4, N=H, K=R, splitk=_splitk(G4, H, R), a_ms=1, a_ks=2 * G4, b_ks=2 * H,
                      b_ns=1, c_ms=H, c_ns=1, dtype=d, atomic=1, out_f32=1, b_mode=2, sh_shift=shift,
                      sh_heads=heads, sh_L=L, sh_edge=edge)
             dwhh.append(g)
-        dwih = torch.zeros(2 * G4, Cp, dtype=F32, device=dev)
+        dwih = _zeros_f32((2 * G4, Cp,), dev)
         gemm_raw(A=dG, B=xn, C=dwih, M=2 * G4, N=Cp, K=R, splitk=_splitk(2 * G4, Cp, R), a_ms=1, a_ks=2 * G4, b_ks=Cp, b_ns=1,
                  c_ms=Cp, c_ns=1, dtype=d, atomic=1, out_f32=1)
         dbias = colsum(dG, R, 2 * G4)
@@ -658,7 +690,7 @@ class MaskISTFT(torch.autograd.Function):
                   "dtt_wcolsum")
             dw = colsum(part, nch, 2 * S * Cc).view(2 * S, Cc)
         else:
-            dw = torch.zeros(2 * S, Cc, dtype=F32, device=dev)
+            dw = _zeros_f32((2 * S, Cc,), dev)
             gemm_raw(A=dmask, B=x, C=dw, M=2 * S, N=Cc, K=P, splitk=_splitk(2 * S, Cc, P), a_ms=1, a_ks=2 * S,
                      b_ks=Cc, b_ns=1, c_ms=Cc, c_ns=1, dtype=d, atomic=1, out_f32=1)
         db = colsum(dmask, P, 2 * S)
@@ -761,7 +793,7 @@ def _linear_bwd(x2d, w, dy2d, need_dx=True):
     if need_dx:
         dx = torch.empty_like(x2d)
         gemm_raw(A=dy2d, B=w, C=dx, M=R, N=K, K=N, a_ms=N, a_ks=1, b_ks=K, b_ns=1, c_ms=K, c_ns=1, dtype=d)
-    dw = torch.zeros(N, K, dtype=F32, device=x2d.device)
+    dw = _zeros_f32((N, K,), x2d.device)
     gemm_raw(A=dy2d, B=x2d, C=dw, M=N, N=K, K=R, splitk=_splitk(N, K, R), a_ms=1, a_ks=N, b_ks=K,
              b_ns=1, c_ms=K, c_ns=1, dtype=d, atomic=1, out_f32=1)
     return dx, dw
@@ -812,7 +844,7 @@ class Conv1x1NormGelu(torch.autograd.Function):
         Co, Ci = wp.shape
         dy = in_gelu_bwd(y, dz.contiguous(), stats)
         dx, dw = _linear_bwd(x.view(-1, Ci), wp, dy.view(-1, Co), ctx.needs_input_grad[0])
-        db = torch.zeros(Co, dtype=F32, device=x.device)       # bias ahead of InstanceNorm: exactly zero
+        db = _zeros_f32((Co,), x.device)       # bias ahead of InstanceNorm: exactly zero
         return (dx.view_as(x) if dx is not None else None), dw.view(ctx.wshape), db
 
 

@@ -223,12 +223,20 @@ def _time_conv(ops, B, Fq, T, Cc, dt, dev, n=20):
     w = (torch.randn(Cc, Cc, 3, 3, device=dev) / (3.0 * Cc ** 0.5))
     bias = torch.zeros(Cc, device=dev)
     wp = ops._pack_fwd(w, "s1", dt)
+    import ctypes as C
+    from dtt_amd._lib import lib, check, ptr, stream_ptr, dtype_code
+    y = torch.empty_like(x)
+    part = torch.empty(B * (4 * ((Fq + 15) // 16) * ((T + 15) // 16) + 4) * Cc * 3, dtype=torch.float32, device=dev)
+
+    def launch():                    # stats = NULL: the kernel with its fused statistics, without the merge launch
+        check(lib().dtt_conv3x3_s1(ptr(x), ptr(wp), ptr(bias), ptr(y), None, ptr(part), None, B, Fq, T, Cc, Cc,
+                                   C.c_float(1e-5), dtype_code(dt), stream_ptr()), "dtt_conv3x3_s1")
     for _ in range(3):
-        ops.conv3x3_s1(x, wp, bias, want_stats=True)
+        launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()                      # torch's current stream == the stream dtt_conv3x3_s1 launches on
     for _ in range(n):
-        ops.conv3x3_s1(x, wp, bias, want_stats=True)
+        launch()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n / 1e3
@@ -238,8 +246,8 @@ def dominant_kernel_roofline(B, precision, dev):
     """The kernel with the largest share of the step (rocprofv3, profiles/): the dedicated 3x3 conv
     conv3x3_s1_kernel<bf16,2> (+ fused InstanceNorm statistics), 70 launches per step over U-Net
     levels 1-3, each 76 GFLOP.  Timed here at the level-1 shape (64 -> 64 channels on [B,257,63]) with
-    events on the launch stream; the events also cover the 11 us conv_stats_finalize launch that
-    dtt_conv3x3_s1 issues behind it, so `achieved` is slightly conservative.  At 288 flop/byte the
+    events on the launch stream, through the C ABI with stats = NULL so that only that kernel runs
+    (not the small conv_stats_finalize launch behind it).  At 288 flop/byte the
     kernel sits at the MFMA side of the ridge (2500 TF / 8 TB/s = 312).  `also` reports the
     full-resolution 32 -> 32 kernel (conv3x3_c32_kernel), which is HBM-bound (144 flop/byte)."""
     from dtt_amd import ops
@@ -256,13 +264,13 @@ def dominant_kernel_roofline(B, precision, dev):
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2: gfx950) / WRITE_SIZE passes at this
-            # exact shape (profiles/r01b_pmc_conv_traffic.txt); algorithmic bytes are 265.3e6
-            "traffic": 308.2e6 if (B == 64 and precision == "bf16") else None,
+            # exact shape (profiles/r01c_pmc_conv_traffic.txt); algorithmic bytes are 265.3e6
+            "traffic": 305.8e6 if (B == 64 and precision == "bf16") else None,
             "avg_launch_us": round(sec * 1e6, 1), "flops_per_launch": flops,
             "also": {"kernel": "conv3x3_c32_kernel (conv3x3 32->32 @ [B,513,126], 33 launches/step)", "bound": "hbm",
                      "achieved": round(bytes0 / sec0 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(bytes0 / sec0 / 8e12, 4), "avg_launch_us": round(sec0 * 1e6, 1),
-                     "traffic": 582.9e6 if (B == 64 and precision == "bf16") else None,
+                     "traffic": 569.8e6 if (B == 64 and precision == "bf16") else None,
                      "bytes_per_launch": bytes0}}
 
 

@@ -503,7 +503,8 @@ __global__ __launch_bounds__(256, CT == 32 ? 2 : 1) void conv3x3_wgrad_kernel(Wg
 #define ST reinterpret_cast<hipStream_t>(stream)
 
 // y = conv3x3_same(x, wp [Co][9][Ci]) + bias (+ res); if partial != NULL also the InstanceNorm
-// statistics: partial scratch of B*(4*tiles_f*tiles_t+4)*Co*3 floats, stats [B][Co][2] = {mean, rstd}.
+// statistics: partial scratch of B*(4*tiles_f*tiles_t+4)*Co*3 floats, stats [B][Co][2] = {mean, rstd}
+// (stats == NULL with partial != NULL: the partials are produced but not merged -- used to time the kernel alone).
 extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, void* y, const void* res,
                               float* partial, float* stats, int B, int F, int T, int Ci, int Co, float eps, int dtype,
                               void* stream) {
@@ -514,7 +515,7 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
         const int total = B * p.tiles_f * p.tiles_t;
         const int tpw = max(1, (total + 511) / 512);         // ONE resident wave of workgroups: 2 per CU x 256 CUs
         hipLaunchKernelGGL(conv3x3_c32_kernel, dim3((total + tpw - 1) / tpw), dim3(256), 0, ST, p, tpw);
-        if (partial)
+        if (partial && stats)
             hipLaunchKernelGGL(conv_c32_stats_finalize, dim3(B), dim3(1024), 0, ST, partial, stats, p.tiles_f * p.tiles_t,
                                tpw, total, (float)F * (float)T, eps);
         DTT_LAUNCH_CHECK();
@@ -531,7 +532,7 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
     if (dtype) { if (tn == 2) LAUNCH(bf16, 2); else LAUNCH(bf16, 1); }
     else { if (tn == 2) LAUNCH(float, 2); else LAUNCH(float, 1); }
 #undef LAUNCH
-    if (partial)
+    if (partial && stats)
         hipLaunchKernelGGL(conv_stats_finalize, dim3((Co + 31) / 32, B), dim3(1024), 0, ST, partial, stats, F, T, Co,
                            p.tiles_f, p.tiles_t, eps);
     DTT_LAUNCH_CHECK();

@@ -128,9 +128,10 @@ int dtt_lstm_fwd_fused(const void* xn, const void* wihp, const void* whhp, const
 
 /* Backward through time over the blocked activations of dtt_lstm_fwd_fused (bf16, H = 256): the
  * autograd of nn.LSTM in latent.py:87-92.  dy [rows][2H], wpt as for dtt_lstm_bwd, dG [rows][2][4H]
- * row-major (consumed by dtt_gemm for dW_ih, dW_hh, dx and by dtt_colsum for the biases). */
-int dtt_lstm_bwd_blk(const void* dy, const void* gates_blk, const float* cst_blk, const void* wpt, void* dG, int N,
-                     int L, int heads, int H, int dtype, void* stream);
+ * row-major (consumed by dtt_gemm for dW_ih, dW_hh, dx); dbias [2][4H] fp32, zeroed by the caller (or NULL),
+ * accumulates the bias gradient (column sums of dG) atomically. */
+int dtt_lstm_bwd_blk(const void* dy, const void* gates_blk, const float* cst_blk, const void* wpt, void* dG,
+                     float* dbias, int N, int L, int heads, int H, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Persistent bidirectional LSTM recurrence, forward and backward through time

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
 // A operand of dh_{t-1} = dG_t * W_hh and the source of the row-major dG rows, written back as
 // 16-byte stores), and the W_hh fragments (512 KB per step) are register-prefetched D k-steps ahead.
 struct LstmBP {
-    const void* dy; const void* gates; const float* cst; const void* wpt; void* dG;
+    const void* dy; const void* gates; const float* cst; const void* wpt; void* dG; float* dbias;
     int N, L, heads, nblk;
 };
 
@@ -573,6 +573,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_blk_kernel(LstmBP p) {
     f32x16_t dhr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dcs[r] = 0.f; dhr[r] = 0.f; }
+    float dbs[4] = {0.f, 0.f, 0.f, 0.f};                   // bias gradient of this lane's 4 gate columns
     const int tl = dir ? 0 : p.L - 1;                      // step processed first
     uint4 dyv[2];
     Vec16<bf16> gv[4][2];
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_blk_kernel(LstmBP p) {
             const float df = dc * cp * fg * (1.f - fg);
             const float dg = dc * ig * (1.f - gg * gg);
             dcs[r] = dc * fg;
+            dbs[0] += di; dbs[1] += df; dbs[2] += dg; dbs[3] += dog_;       // (padding sequences contribute exact zeros)
             bf16* ld = dgbuf + nl * LDG + j;
             stf(ld, di); stf(ld + H, df); stf(ld + 2 * H, dg); stf(ld + 3 * H, dog_);
         }
@@ -643,6 +645,13 @@ __global__ __launch_bounds__(512) void lstm_bwd_blk_kernel(LstmBP p) {
             const int nl = (tid >> 7) + 4 * u, ch = tid & 127;
             const uint4 v = *reinterpret_cast<const uint4*>(dgbuf + nl * LDG + ch * 8);
             if (rbG[u] >= 0) *reinterpret_cast<uint4*>(dG + ((size_t)(rbG[u] + t * p.heads) * 2 + dir) * G4 + ch * 8) = v;
+        }
+    }
+    if (p.dbias) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const float v = dbs[gi] + __shfl_xor(dbs[gi], 32, 64);
+            if (lh == 0) atomicAdd(p.dbias + dir * G4 + gi * H + j, v);
         }
     }
 }
@@ -746,14 +755,15 @@ extern "C" int dtt_lstm_fwd_fused(const void* xn, const void* wihp, const void* 
 }
 
 // Backward through time over the blocked activations written by dtt_lstm_fwd_fused (bf16, H = 256).
-// dy [rows][2H], wpt [2][H/32][4H/16][64][8] (as dtt_lstm_bwd), dG [rows][2][4H] row-major.
+// dy [rows][2H], wpt [2][H/32][4H/16][64][8] (as dtt_lstm_bwd), dG [rows][2][4H] row-major;
+// dbias [2][4H] fp32 (zeroed by the caller, may be NULL) receives the column sums of dG = d(b_ih) = d(b_hh).
 extern "C" int dtt_lstm_bwd_blk(const void* dy, const void* gates_blk, const float* cst_blk, const void* wpt, void* dG,
-                                int N, int L, int heads, int H, int dtype, void* stream) {
+                                float* dbias, int N, int L, int heads, int H, int dtype, void* stream) {
     DTT_CHECK(dtype == 1 && H == 256, "dtt_lstm_bwd_blk: bf16, H = 256 only (got dtype %d, H %d)", dtype, H);
     DTT_CHECK(N > 0 && L > 0 && heads > 0 && N % heads == 0, "dtt_lstm_bwd_blk: bad shape N=%d L=%d", N, L);
     DTT_CHECK(dy && gates_blk && cst_blk && wpt && dG, "dtt_lstm_bwd_blk: null buffer");
     const int nblk = (N + 31) / 32;
-    LstmBP p{dy, gates_blk, cst_blk, wpt, dG, N, L, heads, nblk};
+    LstmBP p{dy, gates_blk, cst_blk, wpt, dG, dbias, N, L, heads, nblk};
     const size_t sm = (size_t)32 * (1024 + 8) * 2 + 32 * (256 + 8) * 2;
     auto k = lstm_bwd_blk_kernel<8>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);

@@ -495,9 +495,11 @@ class DualPathRNN(torch.autograd.Function):
         # recurrent backward
         wpt = torch.stack([_pack_whh_bwd(w_hh, dt), _pack_whh_bwd(w_hh_r, dt)]).contiguous()
         dG = _empty((R, 2, 4 * H), dt, dev)
+        dbias = None
         if blocked:
-            check(lib().dtt_lstm_bwd_blk(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), nslab * heads, L, heads, H,
-                                         d, stream_ptr()), "dtt_lstm_bwd_blk")
+            dbias = _zeros_f32((2 * 4 * H,), dev)           # bias gradient accumulated inside the kernel
+            check(lib().dtt_lstm_bwd_blk(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), ptr(dbias), nslab * heads,
+                                         L, heads, H, d, stream_ptr()), "dtt_lstm_bwd_blk")
         else:
             check(lib().dtt_lstm_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), nslab * heads, L, heads, H, d,
                                      stream_ptr()), "dtt_lstm_bwd")
@@ -512,7 +514,8 @@ class DualPathRNN(torch.autograd.Function):
         dwih = _zeros_f32((2 * G4, Cp,), dev)
         gemm_raw(A=dG, B=xn, C=dwih, M=2 * G4, N=Cp, K=R, splitk=_splitk(2 * G4, Cp, R), a_ms=1, a_ks=2 * G4, b_ks=Cp, b_ns=1,
                  c_ms=Cp, c_ns=1, dtype=d, atomic=1, out_f32=1)
-        dbias = colsum(dG, R, 2 * G4)
+        if dbias is None:
+            dbias = colsum(dG, R, 2 * G4)
         dxn = _empty((nslab, L, Cc), dt, dev)
         gemm_raw(A=dG, B=wih, C=dxn, M=R, N=Cp, K=2 * G4, a_ms=2 * G4, a_ks=1, b_ks=Cp, b_ns=1, c_ms=Cp, c_ns=1,
                  dtype=d)

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_blk_kernel(LstmBP p) {
     f32x16_t dhr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dcs[r] = 0.f; dhr[r] = 0.f; }
-    float dbs[4] = {0.f, 0.f, 0.f, 0.f};                   // bias gradient of this lane's 4 gate columns
+    float dbs0 = 0.f, dbs1 = 0.f;                          // bias gradient of gate columns 2*tid, 2*tid+1
     const int tl = dir ? 0 : p.L - 1;                      // step processed first
     uint4 dyv[2];
     Vec16<bf16> gv[4][2];
@@ -614,7 +614,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_blk_kernel(LstmBP p) {
             const float df = dc * cp * fg * (1.f - fg);
             const float dg = dc * ig * (1.f - gg * gg);
             dcs[r] = dc * fg;
-            dbs[0] += di; dbs[1] += df; dbs[2] += dg; dbs[3] += dog_;       // (padding sequences contribute exact zeros)
             bf16* ld = dgbuf + nl * LDG + j;
             stf(ld, di); stf(ld + H, df); stf(ld + 2 * H, dg); stf(ld + 3 * H, dog_);
         }
@@ -627,6 +626,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_blk_kernel(LstmBP p) {
             }
         }
         __syncthreads();                                  // dG_t complete in LDS
+        if (p.dbias) {                                    // column sums of dG_t (padding sequences hold exact zeros)
+#pragma unroll 8
+            for (int nl = 0; nl < NB; ++nl) {
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(dgbuf + nl * LDG + 2 * tid);
+                dbs0 += __uint_as_float(w << 16);
+                dbs1 += __uint_as_float(w & 0xffff0000u);
+            }
+        }
         // ---- dh_{t-1} = dG_t * W_hh, K = 4H
         if (s > 0) {
 #pragma unroll
@@ -648,11 +655,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_blk_kernel(LstmBP p) {
         }
     }
     if (p.dbias) {
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-            const float v = dbs[gi] + __shfl_xor(dbs[gi], 32, 64);
-            if (lh == 0) atomicAdd(p.dbias + dir * G4 + gi * H + j, v);
-        }
+        atomicAdd(p.dbias + dir * G4 + 2 * tid, dbs0);
+        atomicAdd(p.dbias + dir * G4 + 2 * tid + 1, dbs1);
     }
 }
 

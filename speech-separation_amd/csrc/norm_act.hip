@@ -279,28 +279,50 @@ __global__ __launch_bounds__(NT) void gn_fwd(const T* __restrict__ x, const floa
     const T* xs = x + (int64_t)(o / g.NI) * g.OS + (int64_t)(o % g.NI) * g.IS + cq * EPT;
     const float inv = 1.f / (float)(g.gs * g.L);
     float mean = 0.f, rstd = 0.f;
+    // the thread's rows stay in registers across the three sweeps when they fit (L <= 16 * rpi): one
+    // global read instead of three
+    constexpr int MAXR = 16;
+    const bool keep = g.L <= MAXR * rpi;
+    Vec16<T> rows[MAXR];
+    if (keep && tid < nact) {
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int l = rl + i * rpi;
+            rows[i] = ld16_pred<T>(xs + (int64_t)l * g.RS, xs, l < g.L);
+        }
+    }
+    const int cpg = g.gs / EPT;                             // 16-byte chunks per group
     for (int pass = 0; pass < 2; ++pass) {
         float a = 0.f;
-        if (tid < nact)
-            for (int l = rl; l < g.L; l += rpi) {
-                Vec16<T> v = ld16<T>(xs + (int64_t)l * g.RS);
+        if (tid < nact) {
+            if (keep) {
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) { float d = v.get(e) - mean; a += pass ? d * d : d; }
+                for (int i = 0; i < MAXR; ++i)
+                    if (rl + i * rpi < g.L) {
+#pragma unroll
+                        for (int e = 0; e < EPT; ++e) { float d = rows[i].get(e) - mean; a += pass ? d * d : d; }
+                    }
+            } else {
+                for (int l = rl; l < g.L; l += rpi) {
+                    Vec16<T> v = ld16<T>(xs + (int64_t)l * g.RS);
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) { float d = v.get(e) - mean; a += pass ? d * d : d; }
+                }
             }
+        }
         __syncthreads();
         red[tid] = (tid < nact) ? a : 0.f;
         __syncthreads();
-        if (tid < ng) {
+        if (tid < ng) {                                     // group tid: chunks tid*cpg .. +cpg-1 of every row lane
             float s = 0.f;
-            for (int t = 0; t < nact; ++t)
-                if (((t % cpp) * EPT) / g.gs == tid) s += red[t];
+            for (int r2 = 0; r2 < rpi; ++r2)
+                for (int c2 = 0; c2 < cpg; ++c2) s += red[r2 * cpp + tid * cpg + c2];
             gv[tid] = s * inv;
         }
         __syncthreads();
         if (pass == 0) mean = gv[grp];
         else rstd = rsqrtf(gv[grp] + eps);
     }
-    if (tid < ng && rl == 0) { /* one writer per group: threads tid<ng hold group tid's values in gv */ }
     if (tid < nact && rl == 0 && (cq * EPT) % g.gs == 0) {
         stats[((int64_t)o * ng + grp) * 2] = mean;
         stats[((int64_t)o * ng + grp) * 2 + 1] = rstd;
@@ -312,14 +334,20 @@ __global__ __launch_bounds__(NT) void gn_fwd(const T* __restrict__ x, const floa
             int cp = (cq * EPT + e) % g.Cp;
             ga[e] = gamma[cp]; be[e] = beta[cp];
         }
-        for (int l = rl; l < g.L; l += rpi) {
-            Vec16<T> v = ld16<T>(xs + (int64_t)l * g.RS);
+        auto emit = [&](int l, const Vec16<T>& v) {
             Vec16<T> w;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) w.set(e, (v.get(e) - mean) * rstd * ga[e] + be[e]);
             int64_t oo = ((int64_t)o * g.L + l) * g.C + cq * EPT;
             st16<T>(xn + oo, w);
             if (xperm) st16<T>(xperm + oo, v);
+        };
+        if (keep) {
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i)
+                if (rl + i * rpi < g.L) emit(rl + i * rpi, rows[i]);
+        } else {
+            for (int l = rl; l < g.L; l += rpi) emit(l, ld16<T>(xs + (int64_t)l * g.RS));
         }
     }
 }
@@ -361,8 +389,9 @@ __global__ __launch_bounds__(NT) void gn_bwd(const T* __restrict__ x, const T* _
     __syncthreads();
     if (tid < ng) {
         float s1 = 0.f, s2 = 0.f;
-        for (int t = 0; t < nact; ++t)
-            if (((t % cpp) * EPT) / g.gs == tid) { s1 += r1[t]; s2 += r2[t]; }
+        const int cpg = g.gs / EPT;
+        for (int r2i = 0; r2i < rpi; ++r2i)
+            for (int c2 = 0; c2 < cpg; ++c2) { const int t = r2i * cpp + tid * cpg + c2; s1 += r1[t]; s2 += r2[t]; }
         const float inv = 1.f / (float)(g.gs * g.L);
         g1[tid] = s1 * inv; g2[tid] = s2 * inv;
     }

@@ -498,6 +498,94 @@ __global__ __launch_bounds__(256, CT == 32 ? 2 : 1) void conv3x3_wgrad_kernel(Wg
         }
 }
 
+// Ci = Co = 32 variant: wave w < 3 owns the column shift kw = w (taps kh = 0..2: 48 accumulator
+// registers instead of 144), walks all 18 patch rows with the dy fragments of three rows rolling in
+// registers.  ~130 VGPRs -> three workgroups per CU keep three tiles of loads in flight (the kernel
+// is HBM-bound: 530 MB per launch).
+__global__ __launch_bounds__(256, 3) void conv3x3_wgrad32_kernel(Wg3P p) {
+    constexpr int CT = 32, LD = CT + 8, CPR = CT / 8, NDY = TH * TW * CPR / 256, NX = (PH * PW * CPR + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16 dyl[TH * TW * LD];
+    __shared__ __attribute__((aligned(16))) bf16 xl[PH * PW * LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bf16* dy = reinterpret_cast<const bf16*>(p.dy);
+    const bf16* x = reinterpret_cast<const bf16*>(p.x);
+    const int g = lane >> 4, h = lane >> 5, q = (lane & 15) >> 2, pq = lane & 3;
+    const int colofs = 16 * (g & 1) + 4 * pq;
+    const int kc0 = 8 * h + q;
+    f32x16_t acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int ntiles = p.B * p.tiles_f * p.tiles_t;
+    const int tile0 = blockIdx.x * p.tiles_per_wg, tile1 = min(ntiles, tile0 + p.tiles_per_wg);
+    if (tile0 >= tile1) return;
+    Vec16<bf16> dyr[NDY], xr[NX];
+    auto prefetch = [&](int tile) {
+        int r = tile;
+        const int tt = r % p.tiles_t; r /= p.tiles_t;
+        const int tf = r % p.tiles_f, b = r / p.tiles_f;
+        const int f0 = tf * TH, t0 = tt * TW;
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            const int idx = tid + it * 256, pp = idx / CPR, ch = idx % CPR;
+            const int f = f0 + (pp >> 4), t = t0 + (pp & 15);
+            dyr[it] = ld16_pred<bf16>(dy + (((int64_t)b * p.F + f) * p.T + t) * CT + ch * 8, dy, f < p.F && t < p.T);
+        }
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int idx = tid + it * 256, pp = idx / CPR, ch = idx % CPR;
+            const int pf = pp / PW, pt = pp - pf * PW;
+            const int f = f0 - 1 + pf, t = t0 - 1 + pt;
+            xr[it] = ld16_pred<bf16>(x + (((int64_t)b * p.F + f) * p.T + t) * CT + ch * 8, x,
+                                     idx < PH * PW * CPR && f >= 0 && f < p.F && t >= 0 && t < p.T);
+        }
+    };
+    prefetch(tile0);
+    const int kw = wave;
+    for (int tile = tile0; tile < tile1; ++tile) {
+#pragma unroll
+        for (int it = 0; it < NDY; ++it) {
+            const int idx = tid + it * 256;
+            st16<bf16>(dyl + (idx / CPR) * LD + (idx % CPR) * 8, dyr[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < PH * PW * CPR) st16<bf16>(xl + (idx / CPR) * LD + (idx % CPR) * 8, xr[it]);
+        }
+        __syncthreads();
+        if (tile + 1 < tile1) prefetch(tile + 1);
+        if (wave < 3) {
+            s16x8_t a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0;     // dy fragments of tile rows R, R-1, R-2
+#pragma unroll 2
+            for (int R = 0; R < TH + 2; ++R) {
+                a2 = a1; a1 = a0;
+                if (R < TH) {
+                    const bf16* ap = dyl + (R * 16 + kc0) * LD + colofs;
+                    a0 = tr_frag(ap, ap + 4 * LD);
+                }
+                const bf16* bp = xl + (R * PW + kc0 + kw) * LD + colofs;
+                const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, tr_frag(bp, bp + 4 * LD));
+                if (R < TH) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0), bb, acc[0], 0, 0, 0);
+                if (R >= 1 && R - 1 < TH) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), bb, acc[1], 0, 0, 0);
+                if (R >= 2) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), bb, acc[2], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (wave < 3) {
+        const int lr = lane & 31;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(p.dw + ((int64_t)co * 9 + kh * 3 + kw) * CT + lr, acc[kh][r]);
+            }
+    }
+}
+
 }  // namespace
 
 #define ST reinterpret_cast<hipStream_t>(stream)
@@ -545,6 +633,14 @@ extern "C" int dtt_conv3x3_wgrad(const void* dy, const void* x, float* dw, int B
     DTT_CHECK(dtype == 1, "dtt_conv3x3_wgrad: bf16 only (fp32 goes through dtt_gemm)");
     DTT_CHECK(B > 0 && F > 0 && T > 0 && Ci % 32 == 0 && Co % 32 == 0, "dtt_conv3x3_wgrad: unsupported Ci=%d Co=%d", Ci, Co);
     Wg3P p{dy, x, dw, B, F, T, Ci, Co, (F + TH - 1) / TH, (T + TW - 1) / TW, 1};
+    if (Ci == 32 && Co == 32) {
+        Wg3P q{dy, x, dw, B, F, T, Ci, Co, (F + TH - 1) / TH, (T + TW - 1) / TW, 1};
+        const int nt = B * q.tiles_f * q.tiles_t;
+        q.tiles_per_wg = (nt + 767) / 768;                  // one resident wave: 3 workgroups per CU
+        hipLaunchKernelGGL(conv3x3_wgrad32_kernel, dim3((nt + q.tiles_per_wg - 1) / q.tiles_per_wg), dim3(256), 0, ST, q);
+        DTT_LAUNCH_CHECK();
+        return 0;
+    }
     const int ct = (Ci % 64 == 0 && Co % 64 == 0) ? 64 : 32;
     const int ntiles = B * p.tiles_f * p.tiles_t;
     const int combos = (Co / ct) * (Ci / ct);

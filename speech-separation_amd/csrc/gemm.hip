@@ -629,8 +629,13 @@ struct FastLoader {
     }
 };
 
+// three workgroups per CU: the 128x128 tile needs 138-168 VGPRs, and the compiler's default budget (256)
+// leaves it at two; 170 registers cost nothing (no spills) and hide more of the load -> LDS -> MFMA chain
+#ifndef GEMM_MINB
+#define GEMM_MINB 3
+#endif
 template <typename T, int AK, int BKD, int WGM, int WGN, int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_fast_kernel(const DttGemm p) {
+__global__ __launch_bounds__(256, GEMM_MINB) void gemm_fast_kernel(const DttGemm p) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = sizeof(T) == 2 ? 64 : 32;
     typedef FastLoader<T, AK, BM, BK> LA;
     typedef FastLoader<T, BKD, BN, BK> LB;

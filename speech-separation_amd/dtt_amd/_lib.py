@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdtt_hip.so")
+# DTT_HIP_LIB: another build of the same library (A/B timing of kernel variants)
+_LIB_PATH = os.environ.get("DTT_HIP_LIB") or os.path.join(_HERE, "libdtt_hip.so")
 _lib = None
 
 

@@ -2,7 +2,9 @@
 ResNet-18 lip encoder, tiny AV model) against fixtures generated from the reference."""
 import pytest
 import torch
+import torch.nn.functional as F
 
+import oracle
 from oracle.fill import fill_state_dict, synth_video
 from conftest import load_golden, load_manifest
 from helpers import make_batch, rel_err, grad_close, to_dev
@@ -106,3 +108,81 @@ def test_tiny_xattn_model_fp32():
     assert abs(float(v) - float(fx["metric.SiSnrIPITInference"])) < 0.05
     with pytest.raises(ValueError):
         dtt_amd.DTTNetVisionModel(fusion_method="nope")
+
+
+def test_tiny_film_model_fp32_vs_oracle():
+    """DTTNetPlusModel (FiLM fusion between the latent TFC-TDF and every IDP, DTTNetPlus/modules/latent.py:9-35)
+    end to end on the HIP path against the CPU oracle on the same weights: predictions, PIT loss,
+    permutations (bit-exact) and every parameter gradient.  The oracle's FiLM block and latent are pinned
+    to the reference by tests/golden/film.npz; the composed model is oracle-pinned here."""
+    import dtt_amd
+    g = torch.Generator().manual_seed(31)
+    model = dtt_amd.DTTNetPlusModel(g=8, n_sources=2, n_layers=3, n_idp_layers=2, n_fft=64, hop_length=16,
+                                    n_heads=2, video_embed_dim=24, precision="fp32").to(DEV)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = fill_state_dict(shapes, 17)
+    model.load_state_dict(sd)
+    cpu = make_batch(2, 800, 64, 16, seed=19)
+    feats = torch.randn(2, 5, 2048, generator=g) * 0.1
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    venc = F.linear(feats, sdr["video_encoder.post_processor.weight"], sdr["video_encoder.post_processor.bias"])
+    ref = oracle.dttnet_film_forward(sdr, cpu["spectrogram"], cpu["phase"], cpu["audio_length"], venc,
+                                     n_sources=2, n_heads=2, n_fft=64, hop=16)
+    rl = oracle.pit_loss(cpu["audio"], cpu["sources"], ref["preds"])
+    rl["loss"].backward()
+    b = to_dev(cpu, DEV)
+    out = model(video=feats.to(DEV), **b)
+    for i in range(2):
+        for k in ("audio", "spectrogram", "phase"):
+            e = rel_err(out["preds"][i][k], ref["preds"][i][k])
+            assert e < 5e-4, (i, k, e)                     # two IDPs deep: fp32 envelope of SURVEY section 0 item 6
+    b.update(out)
+    res = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())(**b)
+    assert torch.equal(res["batch_permuts"].cpu(), rl["batch_permuts"])
+    assert rel_err(res["loss"], rl["loss"]) < 1e-5
+    res["loss"].backward()
+    for k, p_ in model.named_parameters():
+        gr = sdr[k].grad
+        if gr is None or float(gr.abs().max()) < 1e-7:        # conv biases ahead of InstanceNorm: exactly 0 here
+            assert p_.grad is None or float(p_.grad.abs().max()) < 1e-5, k
+            continue
+        assert grad_close(p_.grad, gr, 3e-3, atol=1e-3 * float(gr.abs().max()) + 1e-6), k
+
+
+def test_pit_three_sources_vs_oracle():
+    """n_sources = 3: six permutations in itertools order, first minimum wins (pit_loss_wrapper.py:41-71);
+    loss, int64 permutations (bit-exact), gradients and the PIT metrics against the oracle."""
+    import dtt_amd
+    g = torch.Generator().manual_seed(5)
+    B, L, Fq, T = 5, 700, 33, 44
+    def item():
+        return {"audio": torch.randn(B, L, generator=g), "spectrogram": torch.randn(B, Fq, T, generator=g),
+                "phase": torch.randn(B, Fq, T, generator=g)}
+    sources = [item() for _ in range(3)]
+    order = [2, 0, 1]
+    preds = []
+    for i in range(3):                                        # noisy copies of permuted sources -> non-trivial argmin
+        preds.append({k: (sources[order[i]][k] + 0.3 * torch.randn(sources[0][k].shape, generator=g)).requires_grad_(True)
+                      for k in ("audio", "spectrogram", "phase")})
+    audio = sum(s["audio"] for s in sources)
+    rl = oracle.pit_loss(audio, sources, preds)
+    rl["loss"].backward()
+    dpreds = [{k: v.detach().to(DEV).requires_grad_(True) for k, v in p_.items()} for p_ in preds]
+    dsrc = [{k: v.to(DEV) for k, v in s.items()} for s in sources]
+    res = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())(audio=audio.to(DEV), sources=dsrc, preds=dpreds)
+    assert res["batch_permuts"].dtype == torch.int64
+    assert torch.equal(res["batch_permuts"].cpu(), rl["batch_permuts"])
+    assert torch.equal(rl["batch_permuts"], torch.tensor(order).repeat(B, 1))
+    assert rel_err(res["loss"], rl["loss"]) < 1e-5
+    res["loss"].backward()
+    for i in range(3):
+        for k in ("audio", "spectrogram", "phase"):
+            assert rel_err(dpreds[i][k].grad, preds[i][k].grad) < 1e-5, (i, k)
+    dp = [{k: v.detach() for k, v in p_.items()} for p_ in dpreds]
+    cp = [{k: v.detach() for k, v in p_.items()} for p_ in preds]
+    v = dtt_amd.SiSnrIPITTraining()(audio=audio.to(DEV), preds=dp, sources=dsrc, batch_permuts=res["batch_permuts"])
+    r = oracle.pit_metric_training(oracle.si_snr_i, audio, cp, sources, rl["batch_permuts"])
+    assert abs(float(v) - float(r)) < 0.05
+    v = dtt_amd.SiSnrIPITInference()(audio=audio.to(DEV), preds=dp, sources=dsrc)
+    r = oracle.pit_metric_inference(oracle.si_snr_i, audio, cp, sources)
+    assert abs(float(v) - float(r)) < 0.05

@@ -266,3 +266,4 @@ def test_conv3x3_dedicated_kernels(dt, Ci, Co, Fq, T):
         dwp = torch.zeros(Co, 9, Ci, dtype=torch.float32, device=dev)
         check(lib().dtt_conv3x3_wgrad(ptr(_nhwc(dy).to(dev)), ptr(xd), ptr(dwp), Bn, Fq, T, Ci, Co, 1, stream_ptr()), "wgrad")
         assert rel_err(dwp, wr.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)) < TOL[dt]
+

@@ -29,21 +29,31 @@ struct Conv3P {
 // all tiles of one batch item about a fixed pivot, flushed once per (workgroup, wave, batch item).
 struct RunStat { float piv, s1, s2, n; bool open; };
 
-template <typename T, int TN>
-__device__ __forceinline__ void conv3_epilogue(const Conv3P& p, f32x16_t (&acc)[2][TN], float* stage,
+// bias of the lane's output channels (co0 + 32 j + lane % 32), 0 without a bias; loaded by the kernels ahead
+// of their main loop so that no wait for it sits behind the prefetch loads
+template <int TN>
+__device__ __forceinline__ void conv3_bias(const Conv3P& p, int co0, float (&bsv)[TN]) {
+    const float* bp = p.bias ? p.bias : reinterpret_cast<const float*>(&dtt_zero16);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bsv[j] = bp[p.bias ? co0 + j * 32 + (threadIdx.x & 31) : 0];
+}
+
+// RES (fused residual) is a compile-time flag: with a run-time `if (res)` around the loads and another
+// around their use, the compiler sees a path on which the loads stay pending and puts vmcnt(0) in front
+// of the next tile's MFMAs in the persistent kernel -- which serialised its register prefetch.
+template <typename T, int TN, bool RES>
+__device__ __forceinline__ void conv3_epilogue(const Conv3P& p, f32x16_t (&acc)[2][TN], float* stage, const float (&bsv)[TN],
                                                int b, int tf, int tt, int co0, RunStat* run = nullptr) {
     constexpr int BN = 32 * TN, SW = BN + 4, E = Vec16<T>::N, CPP = BN / E, NIT = CPP;   // 64 px * CPP chunks / 64 lanes
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int f0 = tf * TH, t0 = tt * TW;
     T* y = reinterpret_cast<T*>(p.y) + (int64_t)b * p.F * p.T * p.Co;
-    const T* res = p.res ? reinterpret_cast<const T*>(p.res) + (int64_t)b * p.F * p.T * p.Co : nullptr;
-    const float* bp = p.bias ? p.bias : reinterpret_cast<const float*>(&dtt_zero16);
+    const T* res = RES ? reinterpret_cast<const T*>(p.res) + (int64_t)b * p.F * p.T * p.Co : nullptr;
     // statistics are accumulated about a pivot (the slab's first pixel, always inside the image when
     // the slab has any valid pixel) so that sum-of-squares minus square-of-sum does not cancel
-    float bsv[TN], s1[TN], s2[TN], piv[TN];
+    float s1[TN], s2[TN], piv[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        bsv[j] = bp[p.bias ? co0 + j * 32 + lr : 0];
         s1[j] = 0.f; s2[j] = 0.f;
         piv[j] = __shfl(acc[0][j][0] + bsv[j], lr, 64);
     }
@@ -71,7 +81,7 @@ __device__ __forceinline__ void conv3_epilogue(const Conv3P& p, f32x16_t (&acc)[
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     Vec16<T> rv[NIT];
-    if (res) {
+    if constexpr (RES) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int id = lane + it * 64, px = id / CPP, ch = id % CPP;
@@ -89,7 +99,7 @@ __device__ __forceinline__ void conv3_epilogue(const Conv3P& p, f32x16_t (&acc)[
             const float4 s = *reinterpret_cast<const float4*>(stage + px * SW + ch * E + q * 4);
             v[q * 4] = s.x; v[q * 4 + 1] = s.y; v[q * 4 + 2] = s.z; v[q * 4 + 3] = s.w;
         }
-        if (res) {
+        if constexpr (RES) {
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] += rv[it].get(e);
         }
@@ -140,6 +150,8 @@ __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
     const T* x = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.F * p.T * p.Ci;
     const T* wp = reinterpret_cast<const T*>(p.wp);
 
+    float bsv[TN];
+    conv3_bias<TN>(p, co0, bsv);
     f32x16_t acc[2][TN];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -208,12 +220,15 @@ __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
     }
 
     __syncthreads();                                        // operand LDS becomes the output staging area
-    conv3_epilogue<T, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * 64 * (BN + 4), b, tf, tt, co0);
+    float* stage = reinterpret_cast<float*>(smem) + wave * 64 * (BN + 4);
+    if (p.res) conv3_epilogue<T, TN, true>(p, acc, stage, bsv, b, tf, tt, co0);
+    else conv3_epilogue<T, TN, false>(p, acc, stage, bsv, b, tf, tt, co0);
 }
 
 // Specialisation for Ci = Co = 32, bf16 (the full-resolution TFC convs: HBM-bound at 144 flop/byte):
 // persistent workgroups; the 18 KB of weights live in registers for the whole launch; the next tile's
 // patch is prefetched into registers while the current one is in the MFMAs.
+template <bool RES>
 __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles_per_wg) {
     constexpr int LDC = 40, NPC = PH * PW * 4, NIT = (NPC + 255) / 256, SW = 36;
     __shared__ __attribute__((aligned(16))) bf16 patch[PH * PW * LDC];
@@ -242,6 +257,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles
                                       idx < NPC && f >= 0 && f < p.F && t >= 0 && t < p.T);
         }
     };
+    float bsv[1];
+    conv3_bias<1>(p, 0, bsv);
     prefetch(tile0);
     // InstanceNorm partials: one {mean, M2, n} per (batch item, workgroup slot, wave, channel), the slot
     // being the workgroup's index among those that touch the batch item (see conv_c32_stats_finalize)
@@ -259,16 +276,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles
         }
         run.open = false;
     };
-    for (int tile = tile0; tile < tile1; ++tile) {
-        const int b = tile / per_b, rr = tile - b * per_b, tf = rr / p.tiles_t, tt = rr - tf * p.tiles_t;
-        if (b != run_b) { flush(); run_b = b; }
+    auto park = [&]() {                                     // prefetched patch: registers -> LDS
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256;
             if (idx < NPC) st16<bf16>(patch + (idx >> 2) * LDC + (idx & 3) * 8, pre[it]);
         }
-        __syncthreads();
-        if (tile + 1 < tile1) prefetch(tile + 1);
+    };
+    park();
+    __syncthreads();
+    if (tile0 + 1 < tile1) prefetch(tile0 + 1);
+    // Per tile: MFMAs on patch(i) | barrier | patch(i+1) registers -> LDS, prefetch(i+2) issued | epilogue(i)
+    // | barrier.  The wait for the loads of patch(i+1) thus comes a whole MFMA phase after the output
+    // stores of tile i-1 were issued (vmcnt retires in order: a wait placed right after an epilogue
+    // would also wait for that epilogue's stores to be acknowledged).
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int b = tile / per_b, rr = tile - b * per_b, tf = rr / p.tiles_t, tt = rr - tf * p.tiles_t;
+        if (b != run_b) { flush(); run_b = b; }
         f32x16_t acc[2][1];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -287,8 +311,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles
                 }
             }
         }
-        conv3_epilogue<bf16, 1>(p, acc, stage_all + wave * 64 * SW, b, tf, tt, 0, p.partial ? &run : nullptr);
-        __syncthreads();                                    // patch is free for the next tile
+        __syncthreads();                                    // every wave is done reading patch(i)
+        if (tile + 1 < tile1) park();
+        if (tile + 2 < tile1) prefetch(tile + 2);
+        conv3_epilogue<bf16, 1, RES>(p, acc, stage_all + wave * 64 * SW, bsv, b, tf, tt, 0, p.partial ? &run : nullptr);
+        __syncthreads();                                    // patch(i+1) is visible
     }
     flush();
 }
@@ -602,7 +629,8 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
     if (dtype == 1 && Ci == 32 && Co == 32) {
         const int total = B * p.tiles_f * p.tiles_t;
         const int tpw = max(1, (total + 511) / 512);         // ONE resident wave of workgroups: 2 per CU x 256 CUs
-        hipLaunchKernelGGL(conv3x3_c32_kernel, dim3((total + tpw - 1) / tpw), dim3(256), 0, ST, p, tpw);
+        if (res) hipLaunchKernelGGL(conv3x3_c32_kernel<true>, dim3((total + tpw - 1) / tpw), dim3(256), 0, ST, p, tpw);
+        else hipLaunchKernelGGL(conv3x3_c32_kernel<false>, dim3((total + tpw - 1) / tpw), dim3(256), 0, ST, p, tpw);
         if (partial && stats)
             hipLaunchKernelGGL(conv_c32_stats_finalize, dim3(B), dim3(1024), 0, ST, partial, stats, p.tiles_f * p.tiles_t,
                                tpw, total, (float)F * (float)T, eps);

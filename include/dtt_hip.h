@@ -199,6 +199,20 @@ int dtt_bcat_fwd(const void* x, const float* enh, void* out, int B, int F, int T
 int dtt_bcat_bwd(const void* dout, const float* dtok, void* dx, float* denh, int B, int F, int T, int C, int dtype,
                  void* stream);
 
+/* Gradient clip + AdamW over a table of fp32 tensors in two launches (the step after the hot path:
+ * torch.optim.AdamW of train.yaml:20-23 after clip_grad_norm_ of base_trainer.py:478-490, train.yaml:59).
+ * tab / chunks are device arrays; chunks[c] = {tensor index, chunk index} with chunks of
+ * dtt_clip_adamw_chunk() elements; partial: nchunks floats of scratch.  A tensor whose g is NULL is
+ * skipped.  max_norm <= 0 disables clipping; norm_out (may be NULL) receives the unclipped total norm. */
+typedef struct {
+    void* p; const void* g; float* m; float* v;
+    int64_t n;
+    float lr, wd;
+} DttOptTensor;
+int dtt_clip_adamw(const DttOptTensor* tab, int ntensors, const int32_t* chunks, int nchunks, float* partial,
+                   float max_norm, float beta1, float beta2, float eps, int step, float* norm_out, void* stream);
+int dtt_clip_adamw_chunk(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,3 +7,4 @@ from .loss import DTTNetLoss, PITLossWrapper, DTTNetLossWrapper  # noqa: F401
 from .metrics import (SiSnr, SiSnrI, SiSnrPITTraining, SiSnrPITInference, SiSnrIPITTraining,  # noqa: F401
                       SiSnrIPITInference)
 from .ops import stft_mag_phase  # noqa: F401
+from .optim import ClipAdamW  # noqa: F401

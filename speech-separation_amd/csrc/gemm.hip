@@ -559,11 +559,14 @@ struct FastLoader {
     __device__ __forceinline__ void load_conv(const DttGemm& p, int k0, int kmax) {
         int pf = 0, pt = 0;
         if (p.cphase) { pf = (p.cphase - 1) >> 1; pt = (p.cphase - 1) & 1; }
+        // channel counts are powers of two in every DTTNet configuration: no integer division per chunk
+        const bool ci_pow2 = (p.cCi & (p.cCi - 1)) == 0;
+        const int ci_sh = __ffs(p.cCi) - 1;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int gk = k0 + kofs[it];
             bool ok = rok[it] && gk < kmax;
-            const int tap = gk / p.cCi, ci = gk - tap * p.cCi;
+            const int tap = ci_pow2 ? gk >> ci_sh : gk / p.cCi, ci = gk - tap * p.cCi;
             int kh, kw;
             if (p.cphase) { const int nkw = pt ? 2 : 1, ih = tap / nkw; kh = pf ? 2 * ih : 1; kw = pt ? 2 * (tap - ih * nkw) : 1; }
             else { kh = tap / 3; kw = tap - kh * 3; }

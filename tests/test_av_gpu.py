@@ -111,7 +111,7 @@ def test_tiny_xattn_model_fp32():
 
 
 def test_tiny_film_model_fp32_vs_oracle():
-    """DTTNetPlusModel (FiLM fusion between the latent TFC-TDF and every IDP, DTTNetPlus/modules/latent.py:9-35)
+    """DTTNetPlusModel (FiLM fusion between the latent TFC-TDF and the IDP stack, DTTNetPlus/modules/latent.py:9-35)
     end to end on the HIP path against the CPU oracle on the same weights: predictions, PIT loss,
     permutations (bit-exact) and every parameter gradient.  The oracle's FiLM block and latent are pinned
     to the reference by tests/golden/film.npz; the composed model is oracle-pinned here."""
@@ -129,7 +129,10 @@ def test_tiny_film_model_fp32_vs_oracle():
     ref = oracle.dttnet_film_forward(sdr, cpu["spectrogram"], cpu["phase"], cpu["audio_length"], venc,
                                      n_sources=2, n_heads=2, n_fft=64, hop=16)
     rl = oracle.pit_loss(cpu["audio"], cpu["sources"], ref["preds"])
-    rl["loss"].backward()
+    # gradients are compared through a fixed linear functional of the predictions: the L1 loss's sign()
+    # turns the 2e-4 forward differences of a random-weight model into percent-level gradient noise
+    R = [{k: torch.randn(ref["preds"][i][k].shape, generator=g) for k in ("audio", "spectrogram", "phase")} for i in range(2)]
+    sum((ref["preds"][i][k] * R[i][k]).sum() for i in range(2) for k in R[i]).backward()
     b = to_dev(cpu, DEV)
     out = model(video=feats.to(DEV), **b)
     for i in range(2):
@@ -140,11 +143,12 @@ def test_tiny_film_model_fp32_vs_oracle():
     res = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())(**b)
     assert torch.equal(res["batch_permuts"].cpu(), rl["batch_permuts"])
     assert rel_err(res["loss"], rl["loss"]) < 1e-5
-    res["loss"].backward()
+    sum((out["preds"][i][k] * R[i][k].to(DEV)).sum() for i in range(2) for k in R[i]).backward()
     for k, p_ in model.named_parameters():
         gr = sdr[k].grad
-        if gr is None or float(gr.abs().max()) < 1e-7:        # conv biases ahead of InstanceNorm: exactly 0 here
-            assert p_.grad is None or float(p_.grad.abs().max()) < 1e-5, k
+        if k.endswith(".bias") and float(p_.grad.abs().max()) == 0.0:
+            # a conv bias ahead of an affine-free InstanceNorm: exactly 0 here, rounding noise in the oracle
+            assert float(gr.abs().max()) < 1e-4 * float(sdr[k[:-4] + "weight"].grad.abs().max()), k
             continue
         assert grad_close(p_.grad, gr, 3e-3, atol=1e-3 * float(gr.abs().max()) + 1e-6), k
 

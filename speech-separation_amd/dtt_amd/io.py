@@ -1,0 +1,61 @@
+"""Checkpoint interchange with the reference.
+
+The reference saves ``{"arch", "epoch", "state_dict", "optimizer", "lr_scheduler",
+"monitor_best", "config"}`` (base_trainer.py:596-625) and loads either that
+dict or a bare state_dict (HF ``model.pth``), after stripping wrapper prefixes
+(utils.py:77-86) and dropping keys that are unknown or of another shape
+(model_loader.py:199-239).  State-dict names and shapes of the dtt_amd models
+equal the reference's, so its files load directly.  Files are read with
+``weights_only=True``: nothing in the file is executed (the reference itself
+uses ``weights_only=False``)."""
+from __future__ import annotations
+
+import torch
+
+_PREFIXES = ("module.", "model.", "compile.", "_orig_mod.")
+
+
+def align_state_dict_keys(state_dict):
+    """utils.py:77-86: remove DDP / torch.compile / wrapper prefixes wherever they occur in a key."""
+    out = {}
+    for k, v in state_dict.items():
+        for pre in _PREFIXES:
+            k = k.replace(pre, "")
+        out[k] = v
+    return out
+
+
+def load_reference_checkpoint(model, checkpoint, map_location=None):
+    """model_loader.py:199-239.  ``checkpoint``: a path or an already loaded object.  Returns
+    ``(missing, unexpected, skipped)``: ``skipped`` lists the keys dropped for an unknown name or
+    a shape mismatch (the reference drops them silently)."""
+    if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+        if map_location is None:
+            map_location = next(model.parameters()).device
+        checkpoint = torch.load(checkpoint, map_location=map_location, weights_only=True)
+    sd = checkpoint["state_dict"] if isinstance(checkpoint, dict) and "state_dict" in checkpoint else checkpoint
+    sd = align_state_dict_keys(sd)
+    own = model.state_dict()
+    kept, skipped = {}, []
+    for k, v in sd.items():
+        if k in own and tuple(v.shape) == tuple(own[k].shape):
+            kept[k] = v
+        else:
+            skipped.append(k)
+    missing, unexpected = model.load_state_dict(kept, strict=False)
+    return list(missing), list(unexpected), skipped
+
+
+def save_reference_checkpoint(path, model, epoch=0, optimizer=None, lr_scheduler=None, monitor_best=0.0, config=None):
+    """base_trainer.py:596-625: the dict the reference's trainer writes (and ``_resume_checkpoint`` reads)."""
+    state = {
+        "arch": type(model).__name__,
+        "epoch": epoch,
+        "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+        "optimizer": optimizer.state_dict() if optimizer is not None else None,
+        "lr_scheduler": lr_scheduler.state_dict() if lr_scheduler is not None else None,
+        "monitor_best": monitor_best,
+        "config": config,
+    }
+    torch.save(state, path)
+    return state

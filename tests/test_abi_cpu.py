@@ -63,3 +63,33 @@ def test_state_dict_contract():
     for k, v in sd.items():
         assert tuple(v.shape) == man[k], k
     assert sum(p.numel() for p in m.parameters()) == 15166699
+
+
+def test_reference_checkpoint_interchange(tmp_path):
+    """The reference's checkpoint schema (base_trainer.py:596-625) and its loader's key / shape
+    filtering (utils.py:77-86, model_loader.py:199-239), read with weights_only=True."""
+    import dtt_amd
+    torch.manual_seed(0)
+    kw = dict(g=8, n_sources=2, n_layers=3, n_idp_layers=1, n_fft=64, hop_length=16, n_heads=2)
+    a = dtt_amd.DTTNetModel(**kw)
+    b = dtt_amd.DTTNetModel(**kw)
+    opt = torch.optim.AdamW(a.parameters(), lr=1e-3)
+    path = tmp_path / "checkpoint-epoch3.pth"
+    st = dtt_amd.save_reference_checkpoint(path, a, epoch=3, optimizer=opt, monitor_best=1.5, config={"trainer": {"n_epochs": 4}})
+    assert set(st) == {"arch", "epoch", "state_dict", "optimizer", "lr_scheduler", "monitor_best", "config"}
+    assert st["arch"] == "DTTNetModel"
+    missing, unexpected, skipped = dtt_amd.load_reference_checkpoint(b, path, map_location="cpu")
+    assert not missing and not unexpected and not skipped
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(v, w), k
+    # a DDP / torch.compile style state_dict (HF model.pth), one foreign key, one tensor of another shape
+    c = dtt_amd.DTTNetModel(**kw)
+    raw = {"module._orig_mod." + k: v.clone() for k, v in a.state_dict().items()}
+    raw["module.foreign_head.weight"] = torch.zeros(3)
+    key = "encoder.init_conv.weight"
+    raw["module._orig_mod." + key] = torch.zeros(5, 5)
+    before = c.state_dict()[key].clone()
+    missing, unexpected, skipped = dtt_amd.load_reference_checkpoint(c, raw)
+    assert missing == [key] and not unexpected and sorted(skipped) == sorted([key, "foreign_head.weight"])
+    assert torch.equal(c.state_dict()[key], before)
+    assert torch.equal(c.state_dict()["decoder.out_conv.weight"], a.state_dict()["decoder.out_conv.weight"])

@@ -22,7 +22,7 @@ __all__ = [
     "dttnet_forward", "film", "cross_attention_positional", "temporal_aligner",
     "resnet18_video_encoder", "dttnet_vision_forward", "dttnet_film_forward",
     "dttnet_l1", "pit_loss", "fixed_order_loss", "si_snr", "si_snr_i",
-    "pit_metric_training", "pit_metric_inference", "sinusoids",
+    "pit_metric_training", "pit_metric_inference", "sinusoids", "collate",
 ]
 
 
@@ -493,3 +493,40 @@ def pit_metric_inference(metric_fn, audio, preds, sources):
     scores = torch.stack(rows)
     best = scores.argmax(dim=0)
     return (scores[best, torch.arange(B)] / n).mean()
+
+
+# --------------------------------------------------------------------------- #
+# Data-loader boundary (the step before the path)
+# --------------------------------------------------------------------------- #
+def collate(dataset_items):
+    """collate_fn (src/datasets/collate.py:4-83) on items shaped as BaseDataset.__getitem__ makes them
+    (base_dataset.py:72-138): audio [1,L], spectrogram / phase [1,F,T]; zero padding to the longest item."""
+    from torch.nn.utils.rnn import pad_sequence
+
+    def pad_spec(key, src=None):
+        xs = [(it if src is None else it["sources"][src])[key].squeeze(0).transpose(0, 1) for it in dataset_items]
+        return pad_sequence(xs, batch_first=True, padding_value=0.0).transpose(-2, -1)
+
+    def pad_audio(src=None):
+        xs = [(it if src is None else it["sources"][src])["audio"].squeeze(0) for it in dataset_items]
+        return pad_sequence(xs, batch_first=True, padding_value=0.0)
+
+    audio = pad_audio()
+    out = {
+        "spectrogram": pad_spec("spectrogram"), "phase": pad_spec("phase"),
+        "spectrogram_length": torch.tensor([it["spectrogram"].shape[-1] for it in dataset_items]),
+        "audio": audio,
+        "audio_lengths": [it["audio"].shape[-1] for it in dataset_items],
+        "sources": [{"audio": pad_audio(s), "spectrogram": pad_spec("spectrogram", s), "phase": pad_spec("phase", s)}
+                    for s in range(len(dataset_items[0]["sources"]))],
+        "audio_length": audio.shape[-1],
+    }
+    if dataset_items[0].get("mouth1") is not None or dataset_items[0].get("mouth2") is not None:
+        vids = []
+        for it in dataset_items:
+            m1, m2 = it.get("mouth1"), it.get("mouth2")
+            m1 = torch.zeros_like(torch.as_tensor(m2)) if m1 is None else torch.as_tensor(m1)
+            m2 = torch.zeros_like(m1) if m2 is None else torch.as_tensor(m2)
+            vids.append(torch.stack([m1, m2]))
+        out["video"] = torch.stack(vids)
+    return out

@@ -9,3 +9,4 @@ from .metrics import (SiSnr, SiSnrI, SiSnrPITTraining, SiSnrPITInference, SiSnrI
 from .ops import stft_mag_phase  # noqa: F401
 from .optim import ClipAdamW  # noqa: F401
 from .io import load_reference_checkpoint, save_reference_checkpoint, align_state_dict_keys  # noqa: F401
+from .feeder import collate_on_device  # noqa: F401

@@ -7,6 +7,7 @@
 //
 // Row convention of every [rows][...] buffer: row = (outer*L + step)*heads + head;
 // sequence n = outer*heads + head.
+#include <algorithm>
 #include "common.h"
 #include "../../include/dtt_hip.h"
 
@@ -397,9 +398,11 @@ struct LstmBwdP {
 template <typename T, int NP, bool STAGE_ALL>
 __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int H = p.H, kch = p.kch, LDG = kch * H + MM<T>::PAD;
-    constexpr int NB = 32, EPT = MM<T>::EPT;
+    const int H = p.H, kch = p.kch, LDG = kch * H + MM<T>::PAD, LDD = H + 4;
+    constexpr int NB = 32, EPT = MM<T>::EPT, NCH = NP * 16 / EPT;
     T* dgbuf = reinterpret_cast<T*>(smem);                // [NB][LDG]
+    // dh_{t-1} in fp32, [NB][LDD]: overlays dgbuf between the end of a step's GEMM and the next gate math
+    float* dhbuf = reinterpret_cast<float*>(smem);
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
     const int dir = blockIdx.y, n0 = blockIdx.x * NB;
     const int G4 = 4 * H, KS = G4 / 16;
@@ -408,59 +411,86 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
     const T* wpt = reinterpret_cast<const T*>(p.wpt) + (int64_t)dir * G4 * H;
     T* dG = reinterpret_cast<T*>(p.dG);
 
-    int rb[16];
+    // The gate math runs on row-major 16-byte chunks: the 32 x H/EPT chunks of the block's rows are dealt
+    // to the threads NCH apiece (chunk ci = tid + i * blockDim: row ci / cpr, columns EPT * (ci % cpr)), so
+    // gates, cell states and dy arrive as 16-byte vectors and dG leaves as 16-byte vectors (the first form
+    // of this kernel did the math in the MFMA accumulator layout with 2-byte accesses: 120 us per step at
+    // H = 512).  dc stays in registers in this layout; dh comes back from the GEMM through LDS.
+    const int cpr = H / EPT;
+    int rbc[NCH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        rb[r] = n < p.N ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
+    for (int i = 0; i < NCH; ++i) {
+        const int n = n0 + (threadIdx.x + i * blockDim.x) / cpr;
+        rbc[i] = n < p.N ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
     }
-    float dcs[NP][16];
-    f32x16_t dhr[NP];
+    float dcs[NCH][EPT];
 #pragma unroll
-    for (int q = 0; q < NP; ++q)
+    for (int i = 0; i < NCH; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dcs[q][r] = 0.f; dhr[q][r] = 0.f; }
+        for (int e = 0; e < EPT; ++e) dcs[i][e] = 0.f;
 
     for (int s = p.L - 1; s >= 0; --s) {
         const int t = dir ? p.L - 1 - s : s;
         const int tprev = dir ? t + 1 : t - 1;          // forward-pass predecessor step
+        float dhv[NCH][EPT];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int j = (q * nw + wave) * 32 + lr;
+        for (int i = 0; i < NCH; ++i) {
+            const int ci = threadIdx.x + i * blockDim.x, nl = ci / cpr, cc = ci - nl * cpr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const bool ok = rb[r] >= 0;
-                const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
-                const uint32_t rowp = (uint32_t)(ok && s > 0 ? rb[r] + tprev * p.heads : 0);
-                // loads are unconditional (row 0 stands in for out-of-range sequences): a branch per
-                // load would serialise the memory round trips
-                const T* gs = gates + (row * 2u + dir) * (uint32_t)G4 + j;
-                const float ig = ldf(gs), fg = ldf(gs + H), gg = ldf(gs + 2 * H), og = ldf(gs + 3 * H);
-                const float c = p.cst[(row * 2u + dir) * (uint32_t)H + j];
-                const float cpl = p.cst[(rowp * 2u + dir) * (uint32_t)H + j];
-                const float cp = (s > 0) ? cpl : 0.f;
-                const float dh = ldf(dy + (row * 2u + dir) * (uint32_t)H + j) + dhr[q][r];
-                const float tc = tanh_f(c);
+            for (int e4 = 0; e4 < EPT; e4 += 4) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s < p.L - 1) v = *reinterpret_cast<const float4*>(dhbuf + nl * LDD + cc * EPT + e4);
+                dhv[i][e4] = v.x; dhv[i][e4 + 1] = v.y; dhv[i][e4 + 2] = v.z; dhv[i][e4 + 3] = v.w;
+            }
+        }
+        __syncthreads();                                  // every thread holds its dh: the region becomes dgbuf
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ci = threadIdx.x + i * blockDim.x, nl = ci / cpr, cc = ci - nl * cpr;
+            const bool ok = rbc[i] >= 0;
+            // loads are unconditional (row 0 stands in for out-of-range sequences)
+            const uint32_t row = (uint32_t)(ok ? rbc[i] + t * p.heads : 0);
+            const uint32_t rowp = (uint32_t)(ok && s > 0 ? rbc[i] + tprev * p.heads : 0);
+            const T* gs = gates + (row * 2u + dir) * (uint32_t)G4 + cc * EPT;
+            const Vec16<T> vi = ld16<T>(gs), vf = ld16<T>(gs + H), vg = ld16<T>(gs + 2 * H), vo = ld16<T>(gs + 3 * H);
+            const Vec16<T> vdy = ld16<T>(dy + (row * 2u + dir) * (uint32_t)H + cc * EPT);
+            const float* cs = p.cst + (row * 2u + dir) * (uint32_t)H + cc * EPT;
+            const float* cps = p.cst + (rowp * 2u + dir) * (uint32_t)H + cc * EPT;
+            float cv[EPT], cpv[EPT];
+#pragma unroll
+            for (int e4 = 0; e4 < EPT; e4 += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(cs + e4), b = *reinterpret_cast<const float4*>(cps + e4);
+                cv[e4] = a.x; cv[e4 + 1] = a.y; cv[e4 + 2] = a.z; cv[e4 + 3] = a.w;
+                cpv[e4] = b.x; cpv[e4 + 1] = b.y; cpv[e4 + 2] = b.z; cpv[e4 + 3] = b.w;
+            }
+            Vec16<T> oi, of, og_, oo;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const float ig = vi.get(e), fg = vf.get(e), gg = vg.get(e), og = vo.get(e);
+                const float cp = (s > 0) ? cpv[e] : 0.f;
+                const float dh = vdy.get(e) + dhv[i][e];
+                const float tc = tanh_f(cv[e]);
                 float dog_ = dh * tc * og * (1.f - og);
-                const float dc = dcs[q][r] + dh * og * (1.f - tc * tc);
+                const float dc = dcs[i][e] + dh * og * (1.f - tc * tc);
                 float di = dc * gg * ig * (1.f - ig);
                 float df = dc * cp * fg * (1.f - fg);
                 float dg = dc * ig * (1.f - gg * gg);
-                dcs[q][r] = dc * fg;
+                dcs[i][e] = dc * fg;
                 if (!ok) { di = 0.f; df = 0.f; dg = 0.f; dog_ = 0.f; }
-                if (ok) {
-                    T* gd = dG + (row * 2u + dir) * (uint32_t)G4 + j;
-                    stf(gd, di); stf(gd + H, df); stf(gd + 2 * H, dg); stf(gd + 3 * H, dog_);
-                }
-                if (STAGE_ALL) {
-                    T* ld = dgbuf + nl * LDG + j;
-                    stf(ld, di); stf(ld + H, df); stf(ld + 2 * H, dg); stf(ld + 3 * H, dog_);
-                }
+                oi.set(e, di); of.set(e, df); og_.set(e, dg); oo.set(e, dog_);
+            }
+            if (ok) {
+                T* gd = dG + (row * 2u + dir) * (uint32_t)G4 + cc * EPT;
+                st16<T>(gd, oi); st16<T>(gd + H, of); st16<T>(gd + 2 * H, og_); st16<T>(gd + 3 * H, oo);
+            }
+            if (STAGE_ALL) {
+                T* ld = dgbuf + nl * LDG + cc * EPT;
+                st16<T>(ld, oi); st16<T>(ld + H, of); st16<T>(ld + 2 * H, og_); st16<T>(ld + 3 * H, oo);
             }
         }
         if (s == 0) break;
         // ---- dh_{t-1} = dG_t * W_hh, K = 4H
+        f32x16_t dhr[NP];
 #pragma unroll
         for (int q = 0; q < NP; ++q)
 #pragma unroll
@@ -486,20 +516,37 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 const int jt = q * nw + wave;
-                typename MM<T>::Frag bq[2];
-                bq[0] = MM<T>::ldfrag(wpt + (((int64_t)jt * KS + ks0) * 64 + lane) * 8);
-                for (int ks = ks0; ks < ks1; ks += 2) {
+                // W_hh fragments stream from L2: a ring of BD k-steps in flight (one k-step ahead, as this
+                // loop first had it, left every MFMA waiting for an L2 round trip: 128 of them per pass at H = 512)
+                constexpr int BD = 8;
+                typename MM<T>::Frag bq[BD];
+                const T* wq = wpt + ((int64_t)jt * KS * 64 + lane) * 8;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < BD; ++u)
+                    if (ks0 + u < ks1) bq[u] = MM<T>::ldfrag(wq + (int64_t)(ks0 + u) * 512);
+                for (int ks = ks0; ks < ks1; ks += BD) {
+#pragma unroll
+                    for (int u = 0; u < BD; ++u) {
                         const int k = ks + u;
-                        if (k + 1 < ks1) bq[u ^ 1] = MM<T>::ldfrag(wpt + (((int64_t)jt * KS + k + 1) * 64 + lane) * 8);
-                        typename MM<T>::Frag af = MM<T>::ldfrag(dgbuf + lr * LDG + (k - ks0) * 16 + lh * 8);
-                        MM<T>::mma(af, bq[u], dhr[q]);
+                        if (k < ks1) {
+                            typename MM<T>::Frag af = MM<T>::ldfrag(dgbuf + lr * LDG + (k - ks0) * 16 + lh * 8);
+                            MM<T>::mma(af, bq[u], dhr[q]);
+                            if (k + BD < ks1) bq[u] = MM<T>::ldfrag(wq + (int64_t)(k + BD) * 512);
+                        }
                     }
                 }
             }
             __syncthreads();
         }
+        // every wave is done with dgbuf: dh_{t-1} goes to LDS in the accumulator layout, to be picked up
+        // as row-major chunks at the top of the next step
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int j = (q * nw + wave) * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dhbuf[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDD + j] = dhr[q][r];
+        }
+        __syncthreads();
     }
 }
 
@@ -676,6 +723,7 @@ int launch_bwd(LstmBwdP p, int nw, hipStream_t st) {
     int kch = 4;
     while (kch > 1 && (size_t)32 * (kch * p.H + MM<T>::PAD) * sizeof(T) > 150 * 1024) kch >>= 1;
     size_t sm = (size_t)32 * (kch * p.H + MM<T>::PAD) * sizeof(T);
+    sm = std::max(sm, (size_t)32 * (p.H + 4) * sizeof(float));          // dh_{t-1} (fp32) overlays the staging buffer
     DTT_CHECK(sm <= 160 * 1024, "dtt_lstm_bwd: H=%d does not fit LDS", p.H);
     p.kch = kch;
     if (kch == 4) {

@@ -15,6 +15,28 @@ import torch
 from torch import nn
 
 
+_NATIVE_BN = os.environ.get("DTT_VIDEO_NATIVE_BN", "1") == "1"
+
+
+class _NativeBN:
+    """BatchNorm through ATen's own channels-last kernels: MIOpen's NHWC batch-norm kernels took 25 ms of the
+    107 ms cfg4 step (10x the HBM time of the tensors)."""
+
+    def forward(self, x):
+        if not _NATIVE_BN:
+            return super().forward(x)
+        with torch.backends.cudnn.flags(enabled=False):
+            return super().forward(x)
+
+
+class BatchNorm2d(_NativeBN, nn.BatchNorm2d):
+    pass
+
+
+class BatchNorm3d(_NativeBN, nn.BatchNorm3d):
+    pass
+
+
 class Swish(nn.Module):
     def forward(self, x):
         return x * torch.sigmoid(x)
@@ -27,11 +49,11 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.relu1 = Swish()
         self.relu2 = Swish()
         self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
         self.downsample = downsample
 
     def forward(self, x):
@@ -56,14 +78,14 @@ class ResNet18Trunk(nn.Module):
             if isinstance(m, nn.Conv2d):
                 n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
                 m.weight.data.normal_(0, math.sqrt(2.0 / n))
-            elif isinstance(m, nn.BatchNorm2d):
+            elif isinstance(m, nn.BatchNorm2d):  # (BatchNorm2d above is a subclass)
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
 
     def _make(self, planes, blocks, stride):
         ds = None
         if stride != 1 or self.inplanes != planes:
-            ds = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride=stride, bias=False), nn.BatchNorm2d(planes))
+            ds = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride=stride, bias=False), BatchNorm2d(planes))
         layers = [BasicBlock(self.inplanes, planes, stride, ds)]
         self.inplanes = planes
         layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
@@ -84,7 +106,7 @@ class VideoEncoder(nn.Module):
         self.trunk = ResNet18Trunk()
         self.frontend3D = nn.Sequential(
             nn.Conv3d(1, 64, kernel_size=(5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
-            nn.BatchNorm3d(64), Swish(),
+            BatchNorm3d(64), Swish(),
             nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1)))
         if checkpoint_path is not None and os.path.exists(checkpoint_path):
             ck = torch.load(checkpoint_path, map_location="cpu", weights_only=True)

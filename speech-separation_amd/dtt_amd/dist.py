@@ -3,7 +3,7 @@
 The reference has no comm code of its own: HF accelerate wraps the model in
 torch DDP (src/utils/init_utils.py:83-96, train.py:87,101).  This is a
 from-scratch replacement sized for MI355X: gradients live in a few large flat
-fp32 buckets (views, no copies) laid out in reverse-forward order (decoder ->
+fp32 buckets (one multi-tensor gather per bucket) laid out in reverse-forward order (decoder ->
 latent -> encoder, the order backward produces them); a bucket's all-reduce is
 issued asynchronously the moment its last gradient has been accumulated, so
 the collective overlaps the rest of backward.  xGMI is point-to-point, so few

@@ -104,14 +104,11 @@ def conv_wgrad(p_side, q_side, geom, M, N):
     return dwp
 
 
-_SPLITK_TARGET = int(os.environ.get("DTT_SPLITK_TARGET", "512"))
-
-
 def _splitk(M, N, K, batch=1):
     """Split-K factor for an atomically accumulated weight-gradient GEMM: enough workgroups
     (~2-3 per CU) to fill 256 CUs, no more -- every split adds M*N fp32 atomics."""
     tiles = -(-M // 128) * -(-N // 128) * batch
-    return int(max(1, min(128, K // 256, round(_SPLITK_TARGET / tiles))))
+    return int(max(1, min(128, K // 256, round(512 / tiles))))
 
 
 def colsum(x2d, rows, width, ld=None):

@@ -22,19 +22,21 @@ struct LstmP {
     void* gates;         // [rows][2][4H] post-activation i,f,g,o (T)
     float* cst;          // [rows][2][H] cell states (f32)
     int N, L, heads, H;
+    int nb;              // sequences per workgroup: 32, 16 or 8 (the MFMA row tile stays 32; see lstm_block_rows)
 };
 
 // NW = min(8, H/32) waves; the hidden columns are processed in NP = H/(32*NW) sequential passes,
 // wave w owning columns j = (q*NW + w)*32 .. +31 in pass q, all four gates of a column in one lane.
-template <typename T, int PF>
+template <typename T, int PF, int NBT>
 __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = p.H, LDH = H + MM<T>::PAD;
     constexpr int NB = 32;
     T* hbuf = reinterpret_cast<T*>(smem);                 // [2][NB][LDH]
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
-    const int dir = blockIdx.y, n0 = blockIdx.x * NB;
+    const int dir = blockIdx.y, n0 = blockIdx.x * NBT;
     const int KS = H / 16, G4 = 4 * H;
+    constexpr int RMAX = NBT / 2;                       // accumulator rows r < RMAX hold the block's NBT sequences
     const T* xg = reinterpret_cast<const T*>(p.xg);
     const T* wp = reinterpret_cast<const T*>(p.wp) + (int64_t)dir * G4 * H;
     T* y = reinterpret_cast<T*>(p.y);
@@ -42,11 +44,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmP p) {
 
     // per-lane sequence rows of the C layout: r -> local row (r&3)+8(r>>2)+4*lh.
     // rb = row of step 0 of that sequence (-1: beyond N); all offsets fit 32 bits (checked on the host)
-    int rb[16];
+    int rb[RMAX];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        rb[r] = n < p.N ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
+    for (int r = 0; r < RMAX; ++r) {
+        const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh, n = n0 + nl;
+        rb[r] = (n < p.N) ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
     }
     const int NP = H / (32 * nw);
     for (int s = 0; s < p.L; ++s) {
@@ -62,11 +64,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmP p) {
             // the global cst buffer (written by this same lane one step ago, L2-hot)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool ok = rb[r] >= 0;
-                const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
-                const T* src = xg + (row * 2u + dir) * (uint32_t)G4 + jt * 32 + lr;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) { const float v = ldf(src + g * H); acc[g][r] = ok ? v : 0.f; }
+                for (int g = 0; g < 4; ++g) acc[g][r] = 0.f;
+                if (r < RMAX) {                           // rows of the MFMA tile beyond the block cost nothing
+                    const bool ok = rb[r] >= 0;
+                    const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
+                    const T* src = xg + (row * 2u + dir) * (uint32_t)G4 + jt * 32 + lr;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { const float v = ldf(src + g * H); acc[g][r] = ok ? v : 0.f; }
+                }
             }
             // ---- recurrent term h_{t-1} * W_hh^T; W fragments are prefetched one k-step ahead
             if (s > 0) {
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (r >= RMAX) { stf(hn + nl * LDH + j, 0.f); continue; }
                 const bool ok = rb[r] >= 0;
                 const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
                 float ig = sigmoid_f(acc[0][r]), fg = sigmoid_f(acc[1][r]);
@@ -390,6 +397,7 @@ struct LstmBwdP {
     const void* wpt;     // [2][H/32][4H/16][64][8] packed W_hh for dh = dG * W_hh (T)
     void* dG;            // [rows][2][4H] gate pre-activation gradients (T)
     int N, L, heads, H, kch;     // kch: gates staged in LDS per pass (4, 2 or 1)
+    int nb;                      // sequences per workgroup (32, 16 or 8)
 };
 
 // STAGE_ALL: all four gate gradients of a step fit LDS at once and are written there straight from
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
     // dh_{t-1} in fp32, [NB][LDD]: overlays dgbuf between the end of a step's GEMM and the next gate math
     float* dhbuf = reinterpret_cast<float*>(smem);
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
-    const int dir = blockIdx.y, n0 = blockIdx.x * NB;
+    const int dir = blockIdx.y, n0 = blockIdx.x * p.nb;
     const int G4 = 4 * H, KS = G4 / 16;
     const T* dy = reinterpret_cast<const T*>(p.dy);
     const T* gates = reinterpret_cast<const T*>(p.gates);
@@ -420,8 +428,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
     int rbc[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int n = n0 + (threadIdx.x + i * blockDim.x) / cpr;
-        rbc[i] = n < p.N ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
+        const int nl = (threadIdx.x + i * blockDim.x) / cpr, n = n0 + nl;
+        rbc[i] = (nl < p.nb && n < p.N) ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
     }
     float dcs[NCH][EPT];
 #pragma unroll
@@ -448,6 +456,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
         for (int i = 0; i < NCH; ++i) {
             const int ci = threadIdx.x + i * blockDim.x, nl = ci / cpr, cc = ci - nl * cpr;
             const bool ok = rbc[i] >= 0;
+            if (nl >= p.nb) {                                 // rows of the MFMA tile beyond the block: zeros, no traffic
+                if (STAGE_ALL) {
+                    Vec16<T> z;
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) z.set(e, 0.f);
+                    T* ld = dgbuf + nl * LDG + cc * EPT;
+                    st16<T>(ld, z); st16<T>(ld + H, z); st16<T>(ld + 2 * H, z); st16<T>(ld + 3 * H, z);
+                }
+                continue;
+            }
             // loads are unconditional (row 0 stands in for out-of-range sequences)
             const uint32_t row = (uint32_t)(ok ? rbc[i] + t * p.heads : 0);
             const uint32_t rowp = (uint32_t)(ok && s > 0 ? rbc[i] + tprev * p.heads : 0);
@@ -505,9 +523,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
                 for (int idx = threadIdx.x; idx < NB * cpr; idx += blockDim.x) {
                     const int nl = idx / cpr, ch = idx - nl * cpr;
                     const int n = n0 + nl;
-                    const int nn = n < p.N ? n : 0;
+                    const bool okr = nl < p.nb && n < p.N;
+                    const int nn = okr ? n : 0;
                     const uint32_t row = (uint32_t)((nn / p.heads) * p.L * p.heads + (nn % p.heads) + t * p.heads);
-                    Vec16<T> v = ld16_pred<T>(dG + (row * 2u + dir) * (uint32_t)G4 + g0 * H + ch * EPT, dG, n < p.N);
+                    Vec16<T> v = ld16_pred<T>(dG + (row * 2u + dir) * (uint32_t)G4 + g0 * H + ch * EPT, dG, okr);
                     st16<T>(dgbuf + nl * LDG + ch * EPT, v);
                 }
             }
@@ -711,9 +730,12 @@ template <typename T, int PF>
 int launch_fwd(const LstmP& p, int nw, hipStream_t st) {
     size_t sm = (size_t)2 * 32 * (p.H + MM<T>::PAD) * sizeof(T);
     DTT_CHECK(sm <= 160 * 1024, "dtt_lstm_fwd: H=%d does not fit LDS in this dtype", p.H);
-    auto k = lstm_fwd_kernel<T, PF>;
-    if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(k, dim3((p.N + 31) / 32, 2), dim3(nw * 64), sm, st, p);
+    const dim3 grid((p.N + p.nb - 1) / p.nb, 2), block(nw * 64);
+#define LAUNCH_NB(NBT_) do { auto k = lstm_fwd_kernel<T, PF, NBT_>; \
+        if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
+    if (p.nb == 8) LAUNCH_NB(8); else if (p.nb == 16) LAUNCH_NB(16); else LAUNCH_NB(32);
+#undef LAUNCH_NB
     DTT_LAUNCH_CHECK();
     return 0;
 }
@@ -729,14 +751,23 @@ int launch_bwd(LstmBwdP p, int nw, hipStream_t st) {
     if (kch == 4) {
         auto k = lstm_bwd_kernel<T, NP, true>;
         if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k, dim3((p.N + 31) / 32, 2), dim3(nw * 64), sm, st, p);
+        hipLaunchKernelGGL(k, dim3((p.N + p.nb - 1) / p.nb, 2), dim3(nw * 64), sm, st, p);
     } else {
         auto k = lstm_bwd_kernel<T, NP, false>;
         if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k, dim3((p.N + 31) / 32, 2), dim3(nw * 64), sm, st, p);
+        hipLaunchKernelGGL(k, dim3((p.N + p.nb - 1) / p.nb, 2), dim3(nw * 64), sm, st, p);
     }
     DTT_LAUNCH_CHECK();
     return 0;
+}
+
+// Sequences per workgroup of the general kernels.  A workgroup streams all of W_hh every step whatever its
+// row count, but its gate math and activation traffic scale with the rows: when the 32-row blocks leave CUs
+// idle (cfg4: 512 sequences = 32 workgroups) narrower blocks spread that part over more CUs.
+int lstm_block_rows(int N) {
+    int nb = 32;
+    while (nb > 8 && 2 * ((N + nb / 2 - 1) / (nb / 2)) <= 256) nb >>= 1;
+    return nb;
 }
 
 int lstm_shape(int H, int& nw, int& np) {
@@ -753,7 +784,7 @@ extern "C" int dtt_lstm_fwd(const void* xg, const void* wp, void* y, void* gates
     DTT_CHECK(lstm_shape(H, nw, np) == 0 && N > 0 && L > 0 && heads > 0 && N % heads == 0,
               "dtt_lstm_fwd: unsupported shape H=%d N=%d L=%d", H, N, L);
     DTT_CHECK((int64_t)N * L * 8 * H < (1LL << 31), "dtt_lstm_fwd: buffers exceed 32-bit element offsets");
-    LstmP p{xg, wp, y, gates, cst, N, L, heads, H};
+    LstmP p{xg, wp, y, gates, cst, N, L, heads, H, 32};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     DTT_CHECK(cst != nullptr, "dtt_lstm_fwd: cst scratch is required (cell state round-trips through it)");
     if (dtype && H == 256) {
@@ -764,6 +795,7 @@ extern "C" int dtt_lstm_fwd(const void* xg, const void* wp, void* y, void* gates
         DTT_LAUNCH_CHECK();
         return 0;
     }
+    p.nb = lstm_block_rows(N);
     return dtype ? launch_fwd<bf16, 1>(p, nw, st) : launch_fwd<float, 1>(p, nw, st);
 }
 
@@ -773,7 +805,7 @@ extern "C" int dtt_lstm_bwd(const void* dy, const void* gates, const float* cst,
     DTT_CHECK(lstm_shape(H, nw, np) == 0 && N > 0 && L > 0 && heads > 0 && N % heads == 0,
               "dtt_lstm_bwd: unsupported shape H=%d N=%d L=%d", H, N, L);
     DTT_CHECK((int64_t)N * L * 8 * H < (1LL << 31), "dtt_lstm_bwd: buffers exceed 32-bit element offsets");
-    LstmBwdP p{dy, gates, cst, wpt, dG, N, L, heads, H, 4};
+    LstmBwdP p{dy, gates, cst, wpt, dG, N, L, heads, H, 4, lstm_block_rows(N)};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype) {
         if (np == 1) return launch_bwd<bf16, 1>(p, nw, st);

@@ -38,6 +38,12 @@ class GradBucketReducer:
         if cur:
             self._make_bucket(cur)
         self._pending = []
+        # gloo with GPU buckets (rehearsals of the multi-rank path on one GPU): gloo's own asynchronous CUDA
+        # all-reduce hangs when two ranks share a device (seen on the MI355X test boxes with plain torch
+        # tensors too), so that combination is exchanged synchronously through host memory in finish().
+        # RCCL ("nccl") takes the asynchronous path.
+        self._host_staged = (self.world > 1 and dist.get_backend(process_group) == "gloo"
+                             and self.params and self.params[0].is_cuda)
         self._hooks = []
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
@@ -72,6 +78,8 @@ class GradBucketReducer:
                 v.zero_()                                 # parameter unused this step: contributes zero
             p.grad = v
         self._launched[bi] = True
+        if self._host_staged:
+            return                                        # exchanged in finish() through host memory
         self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def zero_grad(self):
@@ -90,6 +98,11 @@ class GradBucketReducer:
         for w in self._pending:
             w.wait()
         self._pending = []
+        if self._host_staged:
+            for flat, _, _ in self.buckets:
+                h = flat.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                flat.copy_(h)
         for flat, _, _ in self.buckets:
             flat.mul_(1.0 / self.world)
 

@@ -79,12 +79,15 @@ def conv_gemm_transposed(x, wp, bias, out, geom):
     w4 = wp.view(Co, 3, 3, Ci)
     for pf in (0, 1):
         for pt in (0, 1):
-            khs = [0, 2] if pf else [1]
-            kws = [0, 2] if pt else [1]
+            # taps {0, 2} or {1} per axis, as slices: indexing with a Python list would build an index tensor
+            # on the host and copy it over synchronously -- a hidden stream sync in the middle of backward
+            # (and, with a collective in flight on another stream, a deadlock between ranks)
+            khs = slice(0, 3, 2) if pf else slice(1, 2)
+            kws = slice(0, 3, 2) if pt else slice(1, 2)
             Fp, Tp = (geom["cFo"] - pf + 1) // 2, (geom["cTo"] - pt + 1) // 2
             if Fp <= 0 or Tp <= 0:
                 continue
-            wq = w4[:, khs][:, :, kws].reshape(Co, -1).contiguous()
+            wq = w4[:, khs, kws].reshape(Co, -1).contiguous()
             kw = dict(A=x, B=wq, C=out, M=geom["cB"] * Fp * Tp, N=Co, K=wq.shape[1], a_ms=0, a_ks=1, b_ks=1,
                       b_ns=wq.shape[1], c_ms=Co, c_ns=1, dtype=_dt(x), a_mode=1, cphase=1 + 2 * pf + pt, **geom)
             if bias is not None:

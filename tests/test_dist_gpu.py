@@ -1,0 +1,102 @@
+"""Two ranks (gloo, both on the one GPU of the test box) through the real path: tiny DTTNet forward +
+PIT loss + backward on the HIP kernels, GradBucketReducer (bucket all-reduce from grad hooks),
+ClipAdamW on the bucket views -- against one process over the concatenated batch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(g=8, n_sources=2, n_layers=3, n_idp_layers=1, n_fft=64, hop_length=16, n_heads=2, precision="fp32")
+
+
+def _setup_paths():
+    for p in (ROOT, os.path.join(ROOT, "speech-separation_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _run_steps(rank, world, steps=2):
+    _setup_paths()
+    import dtt_amd
+    from dtt_amd.dist import GradBucketReducer
+    from helpers import make_batch, to_dev
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    model = dtt_amd.DTTNetModel(**KW).to(dev)
+    red = GradBucketReducer(model, bucket_bytes=64 << 10)     # several buckets
+    opt = dtt_amd.ClipAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5, max_norm=0.5)
+    crit = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())
+    full = make_batch(4, 800, 64, 16, seed=23)
+    per = 4 // world
+    sl = slice(rank * per, (rank + 1) * per)
+
+    def cut(v):
+        return v[sl] if torch.is_tensor(v) else v
+    batch = {k: ([{kk: cut(vv) for kk, vv in d.items()} for d in v] if isinstance(v, list) else cut(v))
+             for k, v in full.items()}
+    batch = to_dev(batch, dev)
+    norms, grads = [], None
+    for _ in range(steps):
+        b = dict(batch)
+        red.zero_grad()
+        b.update(model(**b))
+        b.update(crit(**b))
+        b["loss"].backward()
+        red.finish()
+        if grads is None:
+            grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+        norms.append(float(opt.step()))
+    return {k: v.detach().cpu() for k, v in model.state_dict().items()}, norms, len(red.buckets), grads
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if os.environ.get("DTT_DIST_TRACE"):                      # debugging aid: where does a stuck rank sit
+        import faulthandler
+        f = open(os.path.join(ROOT, "gpurun_out", f"dist_rank{rank}.trace"), "w")
+        faulthandler.dump_traceback_later(45, exit=True, file=f)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sd, norms, nb, grads = _run_steps(rank, world)
+        if rank == 0:
+            q.put(({k: v.numpy() for k, v in sd.items()}, norms, nb, {k: v.numpy() for k, v in grads.items()}))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                                         # the parent must not wait for a result that never comes
+        import traceback
+        q.put(traceback.format_exc())
+        raise
+
+
+def test_two_ranks_match_one_process_over_the_whole_batch():
+    world, port = 2, 31000 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=90)
+    assert not isinstance(res, str), res
+    got, norms, nb, grads = res
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert nb >= 2
+    ref, ref_norms, _, ref_grads = _run_steps(0, 1)
+    for a, b in zip(norms, ref_norms):
+        assert abs(a - b) <= 2e-4 * abs(b), (norms, ref_norms)
+    # the averaged gradients of step 1: only the summation order over the batch differs
+    for k, v in ref_grads.items():
+        g = torch.from_numpy(grads[k])
+        assert float((g - v).norm()) <= 1e-4 * float(v.norm()) + 1e-7, k
+    # parameters after two clipped AdamW steps: Adam's normalised update turns rounding-level gradient
+    # differences of near-zero entries into differences of the order of lr, so the bound is lr-sized
+    for k, v in ref.items():
+        d = (torch.from_numpy(got[k]) - v).abs()
+        assert float(d.max()) <= 2.5e-3, (k, float(d.max()))

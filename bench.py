@@ -266,7 +266,7 @@ def dominant_kernel_roofline(B, precision, dev):
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2: gfx950) / WRITE_SIZE passes at this
-            # exact shape (profiles/r01e_pmc_conv_traffic.txt); algorithmic bytes are 265.3e6
+            # exact shape (profiles/r01f_pmc_conv_traffic.txt); algorithmic bytes are 265.3e6
             "traffic": 305.8e6 if (B == 64 and precision == "bf16") else None,
             "avg_launch_us": round(sec * 1e6, 1), "flops_per_launch": flops,
             "also": {"kernel": "conv3x3_c32_kernel (conv3x3 32->32 @ [B,513,126], 33 launches/step)", "bound": "hbm",

@@ -225,8 +225,15 @@ __global__ __launch_bounds__(NT) void mask_bwd_kernel(const float* __restrict__ 
         dm[2 * s] = ms_ * d_s + mp_ * d_p;
         dm[2 * s + 1] = -mp_ * d_s + ms_ * d_p;
     }
+    if constexpr (sizeof(T) == 2 && S == 2) {              // four bf16 = one 8-byte store instead of four 2-byte ones
+        uint2 pk;
+        pk.x = pack_bf16x2(dm[0], dm[1]);
+        pk.y = pack_bf16x2(dm[2], dm[3]);
+        *reinterpret_cast<uint2*>(dmask + o * 4) = pk;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 2 * S; ++k) stf(dmask + o * 2 * S + k, dm[k]);
+        for (int k = 0; k < 2 * S; ++k) stf(dmask + o * 2 * S + k, dm[k]);
+    }
     T* dxp = dx + o * C;
     for (int c0 = 0; c0 < C; c0 += EPT) {
         Vec16<T> v;

@@ -81,7 +81,7 @@ def test_two_ranks_match_one_process_over_the_whole_batch():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = q.get(timeout=90)
+    res = q.get(timeout=110)
     assert not isinstance(res, str), res
     got, norms, nb, grads = res
     for p in procs:

@@ -207,8 +207,8 @@ __global__ __launch_bounds__(NT) void mask_bwd_kernel(const float* __restrict__ 
     __syncthreads();
     const int tf = threadIdx.x >> 4, tt = threadIdx.x & 15;
     const int f = f0 + tf, t = t0 + tt;
-    if (!(f < F && t < Tn)) return;
-    const int64_t o = ((int64_t)b * F + f) * Tn + t;
+    const bool valid = f < F && t < Tn;
+    const int64_t o = valid ? ((int64_t)b * F + f) * Tn + t : 0;
     const float ms_ = mspec[o], mp_ = mphase[o];
     float dm[2 * S];
 #pragma unroll
@@ -225,26 +225,41 @@ __global__ __launch_bounds__(NT) void mask_bwd_kernel(const float* __restrict__ 
         dm[2 * s] = ms_ * d_s + mp_ * d_p;
         dm[2 * s + 1] = -mp_ * d_s + ms_ * d_p;
     }
-    if constexpr (sizeof(T) == 2 && S == 2) {              // four bf16 = one 8-byte store instead of four 2-byte ones
-        uint2 pk;
-        pk.x = pack_bf16x2(dm[0], dm[1]);
-        pk.y = pack_bf16x2(dm[2], dm[3]);
-        *reinterpret_cast<uint2*>(dmask + o * 4) = pk;
-    } else {
+    if (valid) {
+        if constexpr (sizeof(T) == 2 && S == 2) {          // four bf16 = one 8-byte store instead of four 2-byte ones
+            uint2 pk;
+            pk.x = pack_bf16x2(dm[0], dm[1]);
+            pk.y = pack_bf16x2(dm[2], dm[3]);
+            *reinterpret_cast<uint2*>(dmask + o * 4) = pk;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 2 * S; ++k) stf(dmask + o * 2 * S + k, dm[k]);
+            for (int k = 0; k < 2 * S; ++k) stf(dmask + o * 2 * S + k, dm[k]);
+        }
     }
-    T* dxp = dx + o * C;
-    for (int c0 = 0; c0 < C; c0 += EPT) {
+    // dx = dmask * W: the mask gradients of the tile go through LDS so that consecutive lanes write
+    // consecutive 16-byte pieces (a tile row of 16 pixels is one contiguous run of 16*C elements);
+    // one pixel per lane left every store instruction with 16 bytes per 2C-byte stride
+    float* sdm = tim + S * 16 * 17;
+#pragma unroll
+    for (int k = 0; k < 2 * S; ++k) sdm[threadIdx.x * 2 * S + k] = valid ? dm[k] : 0.f;
+    __syncthreads();
+    const int cpr = C / EPT;
+    for (int id = threadIdx.x; id < 256 * cpr; id += NT) {
+        const int px = id / cpr, ch = id - px * cpr;
+        const int pf = f0 + (px >> 4), pt = t0 + (px & 15);
+        if (pf >= F || pt >= Tn) continue;
+        float dk[2 * S];
+#pragma unroll
+        for (int k = 0; k < 2 * S; ++k) dk[k] = sdm[px * 2 * S + k];
         Vec16<T> v;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < 2 * S; ++k) a += dm[k] * sw[k * C + c0 + e];
+            for (int k = 0; k < 2 * S; ++k) a += dk[k] * sw[k * C + ch * EPT + e];
             v.set(e, a);
         }
-        st16<T>(dxp + c0, v);
+        st16<T>(dx + (((int64_t)b * F + pf) * Tn + pt) * C + ch * EPT, v);
     }
 }
 
@@ -354,7 +369,7 @@ extern "C" int dtt_mask_bwd(const float* w, const float* mspec, const float* mph
     DTT_CHECK(C % ept_of(dtype) == 0 && (S == 2 || S == 1 || S == 3) && imoff >= F && ldz >= imoff + F,
               "dtt_mask_bwd: bad shape C=%d S=%d", C, S);
     dim3 grid((F + 15) / 16, (T + 15) / 16, B);
-    size_t sm = (size_t)(2 * S * C + 2 * S * 16 * 17) * sizeof(float);
+    size_t sm = (size_t)(2 * S * C + 2 * S * 16 * 17 + 256 * 2 * S) * sizeof(float);
 #define MB(TT, SS) hipLaunchKernelGGL((mask_bwd_kernel<TT, SS>), grid, dim3(NT), sm, ST, w, mspec, mphase, pspec, pphase, dspec, dphase, dZ, (TT*)dx, (TT*)dmask, B, F, T, C, ldz, imoff)
     if (dtype) { if (S == 1) MB(bf16, 1); else if (S == 2) MB(bf16, 2); else MB(bf16, 3); }
     else { if (S == 1) MB(float, 1); else if (S == 2) MB(float, 2); else MB(float, 3); }

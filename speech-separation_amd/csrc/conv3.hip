@@ -492,9 +492,13 @@ __global__ __launch_bounds__(256, CT == 32 ? 2 : 1) void conv3x3_wgrad_kernel(Wg
         // Walk the PATCH rows R: the x fragment of (row R, column shift kw) feeds the taps kh = 0..2 of
         // the output rows kr = R - kh, so each is read from LDS once instead of three times.
         s16x8_t a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0;     // dy fragments of rows R, R-1, R-2
-        for (int R = kr_lo; R < kr_hi + 2; ++R) {
+        // CT == 64: bounds are compile-time (0 .. TH + 1), the walk is fully unrolled and the row guards fold away
+#pragma unroll
+        for (int Ri = 0; Ri < (CT == 64 ? TH + 2 : 6); ++Ri) {
+            constexpr int NR = CT == 64 ? TH : 4;          // output rows this wave contracts over
+            const int R = kr_lo + Ri;
             a2 = a1; a1 = a0;
-            if (R < kr_hi) {
+            if (Ri < NR) {
                 const bf16* ap = dyl + (R * 16 + kc0) * LD + wm * 32 + colofs;
                 a0 = tr_frag(ap, ap + 4 * LD);
             }
@@ -503,11 +507,11 @@ __global__ __launch_bounds__(256, CT == 32 ? 2 : 1) void conv3x3_wgrad_kernel(Wg
                 const bf16* bp = xl + (R * PW + kc0 + kw) * LD + wn * 32 + colofs;
                 const s16x8_t bfv = tr_frag(bp, bp + 4 * LD);
                 const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, bfv);
-                if (R < kr_hi)                                   // kh = 0, kr = R
+                if (Ri < NR)                                     // kh = 0, kr = R
                     acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0), bb, acc[kw], 0, 0, 0);
-                if (R - 1 >= kr_lo && R - 1 < kr_hi)             // kh = 1
+                if (Ri >= 1 && Ri - 1 < NR)                      // kh = 1
                     acc[3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), bb, acc[3 + kw], 0, 0, 0);
-                if (R - 2 >= kr_lo)                              // kh = 2
+                if (Ri >= 2)                                     // kh = 2
                     acc[6 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), bb, acc[6 + kw], 0, 0, 0);
             }
         }
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad32_kernel(Wg3P p) {
         if (tile + 1 < tile1) prefetch(tile + 1);
         if (wave < 3) {
             s16x8_t a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0;     // dy fragments of tile rows R, R-1, R-2
-#pragma unroll 2
+#pragma unroll
             for (int R = 0; R < TH + 2; ++R) {
                 a2 = a1; a1 = a0;
                 if (R < TH) {

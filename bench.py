@@ -32,8 +32,10 @@ WORKLOADS = {
     "xattn60m": dict(model="xattn", g=32, n_idp=4, batch=16, seconds=2.0, fwd_gflop_per_item=271.3),
     # configs[2]: DTTNet AV FiLM 25M, B=64 x 2 s (lip features precomputed: frozen 3rd-party front end not built)
     "film25m": dict(model="film", g=32, n_idp=4, batch=64, seconds=2.0, fwd_gflop_per_item=96.6),
+    # configs[4]: DTTNet AV cross-attention 200M (g = 64), B=16 x 6 s long-utterance stress (T = 376 frames, H = 1024 LSTMs)
+    "xattn200m": dict(model="xattn", g=64, n_idp=4, batch=16, seconds=6.0, fwd_gflop_per_item=2605.0),
 }
-NAMES = {"audio": "DTTNet audio-only 15M", "xattn": "DTTNet AV cross-attention 60M (ResNet-18 lip encoder in the step)",
+NAMES = {"audio": "DTTNet audio-only 15M", "xattn": "DTTNet AV cross-attention (ResNet-18 lip encoder in the step)",
          "film": "DTTNet AV FiLM (lip features precomputed)"}
 
 

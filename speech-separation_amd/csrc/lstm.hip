@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwdP p) {
             }
         }
         __syncthreads();                                  // every thread holds its dh: the region becomes dgbuf
-#pragma unroll
+#pragma unroll (NP >= 4 ? 2 : NCH)
         for (int i = 0; i < NCH; ++i) {
             const int ci = threadIdx.x + i * blockDim.x, nl = ci / cpr, cc = ci - nl * cpr;
             const bool ok = rbc[i] >= 0;

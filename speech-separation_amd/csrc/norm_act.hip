@@ -187,18 +187,30 @@ __global__ __launch_bounds__(NT) void in_gelu_bwd_partial(const T* __restrict__ 
     for (int c = tid; c < C; c += NT) dst[c * 2 + 1] = chv[c];
 }
 
-// sums[b][c][2] = sum over chunks / n
-__global__ void in_bwd_finalize(const float* __restrict__ partial, float* __restrict__ sums, int C, int nchunks,
-                                float inv_n) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (c >= C) return;
+// sums[b][c][2] = sum over chunks / n.  One workgroup per (32 channels, b): 8 groups of lanes take every
+// eighth chunk (a serial walk over all chunks by one lane per channel cost 10-24 us per launch, 48 launches
+// per step), then a fixed-order merge through LDS (deterministic).
+__global__ __launch_bounds__(256) void in_bwd_finalize(const float* __restrict__ partial, float* __restrict__ sums, int C,
+                                                       int nchunks, float inv_n) {
+    __shared__ float sh[2][8][33];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl, b = blockIdx.y;
     float a = 0.f, q = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-        const float* s = partial + (((int64_t)b * nchunks + k) * C + c) * 2;
-        a += s[0]; q += s[1];
+    if (c < C) {
+        for (int k = g; k < nchunks; k += 8) {
+            const float2 s = *reinterpret_cast<const float2*>(partial + (((int64_t)b * nchunks + k) * C + c) * 2);
+            a += s.x; q += s.y;
+        }
     }
-    sums[((int64_t)b * C + c) * 2] = a * inv_n;
-    sums[((int64_t)b * C + c) * 2 + 1] = q * inv_n;
+    sh[0][g][cl] = a; sh[1][g][cl] = q;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float ta = 0.f, tq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ta += sh[0][i][cl]; tq += sh[1][i][cl]; }
+        sums[((int64_t)b * C + c) * 2] = ta * inv_n;
+        sums[((int64_t)b * C + c) * 2 + 1] = tq * inv_n;
+    }
 }
 
 // dy = rstd * (dyh - m1 - yh*m2) over the full plane; same thread layout as in_gelu_fwd
@@ -582,7 +594,7 @@ extern "C" int dtt_in_gelu_bwd(const void* y, const void* dz, const float* stats
     size_t sm = (NT * ept + C) * sizeof(float);
     if (dtype) hipLaunchKernelGGL(in_gelu_bwd_partial<bf16>, dim3(nch, B), dim3(NT), sm, ST, (const bf16*)y, (const bf16*)dz, stats, partial, Fy, Ty, Fz, Tz, C, chunk);
     else hipLaunchKernelGGL(in_gelu_bwd_partial<float>, dim3(nch, B), dim3(NT), sm, ST, (const float*)y, (const float*)dz, stats, partial, Fy, Ty, Fz, Tz, C, chunk);
-    hipLaunchKernelGGL(in_bwd_finalize, dim3((C + 127) / 128, B), dim3(128), 0, ST, partial, sums, C, nch, 1.f / (float)P);
+    hipLaunchKernelGGL(in_bwd_finalize, dim3((C + 31) / 32, B), dim3(256), 0, ST, partial, sums, C, nch, 1.f / (float)P);
     const int ech = ew_chunk(B, P, C / ept);
     dim3 grid((P + ech - 1) / ech, B);
     if (dtype) hipLaunchKernelGGL(in_gelu_bwd_apply<bf16>, grid, dim3(NT), 0, ST, (const bf16*)y, (const bf16*)dz, stats, sums, (bf16*)dy, Fy, Ty, Fz, Tz, C, ech);

@@ -89,8 +89,10 @@ def test_two_ranks_match_one_process_over_the_whole_batch():
         assert p.exitcode == 0
     assert nb >= 2
     ref, ref_norms, _, ref_grads = _run_steps(0, 1)
-    for a, b in zip(norms, ref_norms):
-        assert abs(a - b) <= 2e-4 * abs(b), (norms, ref_norms)
+    # step 1: same weights, only the batch summation order differs; step 2 starts from weights that already
+    # differ by Adam's lr-sized rounding noise (see the parameter bound below)
+    for a, b, tol in zip(norms, ref_norms, (1e-4, 3e-3)):
+        assert abs(a - b) <= tol * abs(b), (norms, ref_norms)
     # the averaged gradients of step 1: only the summation order over the batch differs
     for k, v in ref_grads.items():
         g = torch.from_numpy(grads[k])

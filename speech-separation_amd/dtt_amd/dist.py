@@ -22,7 +22,7 @@ class GradBucketReducer:
     re-pointed at the views, and the bucket's all-reduce is issued asynchronously.  With one process
     (world size 1) nothing is exchanged and the reducer is a pass-through."""
 
-    def __init__(self, module, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, module, bucket_bytes=32 << 20, process_group=None, broadcast_state=True):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -44,6 +44,8 @@ class GradBucketReducer:
         # RCCL ("nccl") takes the asynchronous path.
         self._host_staged = (self.world > 1 and dist.get_backend(process_group) == "gloo"
                              and self.params and self.params[0].is_cuda)
+        if self.world > 1 and broadcast_state:
+            self.broadcast_state(module)
         self._hooks = []
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
@@ -51,6 +53,19 @@ class GradBucketReducer:
             for bi, (_, ps, _) in enumerate(self.buckets):
                 for p in ps:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
+    def broadcast_state(self, module):
+        """One-time copy of rank 0's parameters and buffers to every rank (what DDP's constructor does for the
+        reference, init_utils.py:83-96): replicas start identical whatever each rank's seed was."""
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                if self._host_staged:
+                    h = t.detach().cpu()
+                    dist.broadcast(h, src=src, group=self.group)
+                    t.copy_(h)
+                else:
+                    dist.broadcast(t.detach(), src=src, group=self.group)
 
     def _make_bucket(self, ps):
         n = sum(p.numel() for p in ps)

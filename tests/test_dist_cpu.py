@@ -17,13 +17,13 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dtt_amd.dist import GradBucketReducer
-    torch.manual_seed(0)
+    torch.manual_seed(rank)                  # replicas start different: the reducer copies rank 0's state
     net = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, 40), torch.nn.Tanh(),
-                              torch.nn.Linear(40, 3), torch.nn.Linear(3, 3))
-    for p in net[5].parameters():            # a parameter that never gets a gradient in step 2
-        pass
+                              torch.nn.Linear(40, 3), torch.nn.Linear(3, 3))   # net[5] gets no gradient in step 2
+    net.register_buffer("steps_seen", torch.tensor([7 + rank]))
     red = GradBucketReducer(net, bucket_bytes=1000)        # several buckets
     assert len(red.buckets) >= 2
+    assert int(net.steps_seen) == 7
     g = torch.Generator().manual_seed(100)
     x_all = torch.randn(2, 2 * world, 12, generator=g)
     out = []

@@ -190,6 +190,9 @@ int dtt_sisnr(const float* est, const float* const* src, float* partial, float* 
  * (cross_attention_positional.py:55,77-78).
  * ------------------------------------------------------------------------- */
 int dtt_binary(int op, const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+/* Packed weight of the data-gradient conv of a stride-1 conv3x3 (autograd of F.conv2d, block_tfc_tdf.py:12-17):
+ * w fp32 [Co][Ci][3][3] -> out [Ci][9][Co] with the taps rotated by 180 degrees, cast to dtype. */
+int dtt_pack_conv3_dgrad(const float* w, void* out, int Co, int Ci, int dtype, void* stream);
 int dtt_film_fwd(const void* x, const float* gbc, const float* gbf, void* y, int B, int F, int T, int C, int dtype,
                  void* stream);
 int dtt_film_bwd(const void* x, const void* dy, const float* gbc, const float* gbf, void* dx, float* dgbc,

@@ -161,6 +161,18 @@ __global__ __launch_bounds__(NT) void bcat_bwd_kernel(const T* __restrict__ dout
     }
 }
 
+// Weight of a stride-1 conv3x3 for its data-gradient conv: out[ci][tap][co] = w[co][ci][8 - tap]
+// (taps rotated by 180 degrees, channels swapped, cast), one launch instead of flip + permuted copy.
+template <typename T>
+__global__ __launch_bounds__(NT) void pack_conv3_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int Co,
+                                                              int Ci) {
+    const int total = Ci * 9 * Co;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
+        const int co = i % Co, r = i / Co, tap = r % 9, ci = r / 9;
+        stf(out + i, w[((int64_t)co * Ci + ci) * 9 + (8 - tap)]);
+    }
+}
+
 int ept_of(int dtype) { return dtype ? 8 : 4; }
 int grid_for(int64_t total) { int64_t g = (total + NT - 1) / NT; return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192); }
 }  // namespace
@@ -176,6 +188,15 @@ extern "C" int dtt_binary(int op, const void* a, const void* b, void* out, int64
     if (dtype) { if (op) BK(bf16, 1); else BK(bf16, 0); }
     else { if (op) BK(float, 1); else BK(float, 0); }
 #undef BK
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_pack_conv3_dgrad(const float* w, void* out, int Co, int Ci, int dtype, void* stream) {
+    DTT_CHECK(w && out && Co > 0 && Ci > 0 && (int64_t)Co * Ci * 9 < (1LL << 31), "dtt_pack_conv3_dgrad: bad shape Co=%d Ci=%d", Co, Ci);
+    const int grid = grid_for((int64_t)Co * Ci * 9);
+    if (dtype) hipLaunchKernelGGL(pack_conv3_dgrad_kernel<bf16>, dim3(grid), dim3(NT), 0, ST, w, (bf16*)out, Co, Ci);
+    else hipLaunchKernelGGL(pack_conv3_dgrad_kernel<float>, dim3(grid), dim3(NT), 0, ST, w, (float*)out, Co, Ci);
     DTT_LAUNCH_CHECK();
     return 0;
 }

@@ -241,6 +241,11 @@ def _pack_fwd(w, kind, dt):
 
 def _pack_dgrad(w, kind, dt):
     if kind == "s1":
+        if w.dtype == F32 and w.is_contiguous() and w.shape[2:] == (3, 3):
+            out = torch.empty((w.shape[1], 9 * w.shape[0]), dtype=dt, device=w.device)
+            check(lib().dtt_pack_conv3_dgrad(ptr(w), ptr(out), w.shape[0], w.shape[1], 1 if dt == torch.bfloat16 else 0,
+                                             stream_ptr()), "dtt_pack_conv3_dgrad")
+            return out
         return _cast_perm(w.flip(2, 3), (1, 2, 3, 0), dt).view(w.shape[1], -1)
     if kind == "down":
         return _cast_perm(w, (1, 2, 3, 0), dt).view(w.shape[1], -1)

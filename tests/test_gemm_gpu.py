@@ -267,3 +267,16 @@ def test_conv3x3_dedicated_kernels(dt, Ci, Co, Fq, T):
         check(lib().dtt_conv3x3_wgrad(ptr(_nhwc(dy).to(dev)), ptr(xd), ptr(dwp), Bn, Fq, T, Ci, Co, 1, stream_ptr()), "wgrad")
         assert rel_err(dwp, wr.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)) < TOL[dt]
 
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Co,Ci", [(32, 32), (64, 24), (8, 136)])
+def test_pack_conv3_dgrad_is_the_rotated_transpose(dt, Co, Ci):
+    """One-launch pack of the data-gradient conv's weight: bit-exact against flip + permute + cast."""
+    from dtt_amd import ops
+    torch.manual_seed(5)
+    w = torch.randn(Co, Ci, 3, 3, device="cuda")
+    got = ops._pack_dgrad(w, "s1", dt)
+    ref = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, 9 * Co).to(dt)
+    assert got.shape == ref.shape and got.dtype == dt
+    assert torch.equal(got, ref)

@@ -7,7 +7,7 @@ fp32 buckets (one multi-tensor gather per bucket) laid out in reverse-forward or
 latent -> encoder, the order backward produces them); a bucket's all-reduce is
 issued asynchronously the moment its last gradient has been accumulated, so
 the collective overlaps the rest of backward.  xGMI is point-to-point, so few
-large messages beat many small ones: the default bucket is 32 MiB.
+large messages beat many small ones: the default bucket is 32 MiB (a quarter of the gradients for small models).
 """
 from __future__ import annotations
 
@@ -22,10 +22,15 @@ class GradBucketReducer:
     re-pointed at the views, and the bucket's all-reduce is issued asynchronously.  With one process
     (world size 1) nothing is exchanged and the reducer is a pass-through."""
 
-    def __init__(self, module, bucket_bytes=32 << 20, process_group=None, broadcast_state=True):
+    def __init__(self, module, bucket_bytes=None, process_group=None, broadcast_state=True):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
+        if bucket_bytes is None:
+            # the LAST bucket's all-reduce is the one backward cannot hide: at most 32 MiB, but at least four
+            # buckets for a small model (15M parameters = 60 MB of gradients -> 15 MB buckets), never under 4 MiB
+            total = 4 * sum(p.numel() for p in self.params)
+            bucket_bytes = min(32 << 20, max(4 << 20, total // 4))
         params = list(reversed(self.params))              # backward order ~ reverse registration order
         self.buckets = []                                 # (flat, [params], [views])
         cur, cur_n = [], 0

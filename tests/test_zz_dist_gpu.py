@@ -102,3 +102,15 @@ def test_two_ranks_match_one_process_over_the_whole_batch():
     for k, v in ref.items():
         d = (torch.from_numpy(got[k]) - v).abs()
         assert float(d.max()) <= 2.5e-3, (k, float(d.max()))
+
+
+def test_reducer_async_path_over_rccl_one_rank():
+    """The RCCL ("nccl") leg of GradBucketReducer -- asynchronous bucket all-reduces issued from the grad hooks, waits in
+    finish() -- on the one GPU a test box has: a one-rank group with the reducer told the world is 2, so every
+    collective runs (sums over one rank are identities) and the gradients must come out exactly halved.  Own process:
+    the process group must not leak into the other tests."""
+    import subprocess
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_single_rank_probe.py")
+    r = subprocess.run([sys.executable, "-u", script], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rccl single-rank probe ok" in r.stdout

@@ -15,6 +15,30 @@ __device__ __forceinline__ void reduce_channels(const float (&v)[EPT], float* re
                                                 int C) {
     const int tid = threadIdx.x;
     __syncthreads();
+    if (cpp <= 32 && (cpp & (cpp - 1)) == 0) {
+        // cpp divides the wave: the lanes of a channel chunk are lane % cpp apart, so the wave folds itself by
+        // xor-shuffles and only NT/64 rows of C floats go through LDS (the general walk below costs ~5 us per
+        // workgroup at C = 32: 64 dependent LDS reads by 32 threads, twice per kernel)
+        float w[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) w[e] = (tid < nact) ? v[e] : 0.f;
+        for (int off = cpp; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) w[e] += __shfl_xor(w[e], off, 64);
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane < cpp)
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) red[wave * C + lane * EPT + e] = w[e];
+        __syncthreads();
+        for (int c = tid; c < C; c += NT) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < NT / 64; ++k) s += red[k * C + c];
+            out[c] = s;
+        }
+        __syncthreads();
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) red[tid * EPT + e] = (tid < nact) ? v[e] : 0.f;
     __syncthreads();

@@ -149,7 +149,9 @@ int dtt_lstm_bwd(const void* dy, const void* gates, const float* cst, const void
  * STFT / iSTFT glue (base_dataset.py:154-167; model_dttnet.py:77-85), the 1x1
  * input conv (encoder.py:26-27) and the fused out conv + mask + torch.polar
  * (decoder.py:29; model_dttnet.py:47-78) with its backward (incl. polar's
- * sgn() autograd rule).
+ * sgn() autograd rule).  Z (the complex spectrum handed to the inverse DFT,
+ * re at column f, im at imoff + f) is float32 in every mode: torch.polar /
+ * torch.istft stay complex64 under bf16 autocast.
  * ------------------------------------------------------------------------- */
 int dtt_reflect_pad(const float* x, float* xp, int B, int L, int pad, void* stream);
 int dtt_stft_post(const float* reim, float* mag, float* phase, int B, int F, int T, int ld, int imoff,
@@ -215,6 +217,17 @@ typedef struct {
 int dtt_clip_adamw(const DttOptTensor* tab, int ntensors, const int32_t* chunks, int nchunks, float* partial,
                    float max_norm, float beta1, float beta2, float eps, int step, float* norm_out, void* stream);
 int dtt_clip_adamw_chunk(void);
+/* The same update with (a) the step count read from device memory (step_dev, int32: a captured HIP graph replays
+ * with the count its caller increments on the device; NULL: use `step`), (b) an externally merged total squared
+ * gradient norm (sumsq_dev; NULL: computed here) -- the sharded step of train.yaml:20-31,59 under data parallelism:
+ * reduce-scatter, dtt_grad_sumsq on the shard, all-reduce of one float, this update on the shard, all-gather --
+ * and (c) grad_scale folded into the clip coefficient (1 / world when the collective summed).
+ * dtt_grad_sumsq: sum of squares of every gradient in tab, merged in a fixed order into sumsq_out[0]. */
+int dtt_grad_sumsq(const DttOptTensor* tab, int ntensors, const int32_t* chunks, int nchunks, float* partial,
+                   float* sumsq_out, void* stream);
+int dtt_clip_adamw_ex(const DttOptTensor* tab, int ntensors, const int32_t* chunks, int nchunks, float* partial,
+                      float max_norm, float beta1, float beta2, float eps, int step, const int32_t* step_dev,
+                      const float* sumsq_dev, float grad_scale, float* norm_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ __all__ = [
     "stft_complex", "stft_mag_phase", "istft_rect", "conv_norm_gelu", "tfc_tdf",
     "encoder", "lstm_bidir", "tc_fc_rnn", "idp", "latent", "decoder", "mask_recon",
     "dttnet_forward", "film", "cross_attention_positional", "temporal_aligner",
-    "resnet18_video_encoder", "dttnet_vision_forward", "dttnet_film_forward",
+    "resnet18_video_encoder", "lipreading_video_features", "dttnet_vision_forward", "dttnet_film_forward",
     "dttnet_l1", "pit_loss", "fixed_order_loss", "si_snr", "si_snr_i",
     "pit_metric_training", "pit_metric_inference", "sinusoids", "collate",
 ]
@@ -397,6 +397,50 @@ def resnet18_video_encoder(sd, p, video, training=True):
             x = _swish(y + r)
     x = x.mean(dim=(2, 3))                                    # AdaptiveAvgPool2d(1)
     return x.view(B, N, T, -1).transpose(2, 3)
+
+
+def lipreading_video_features(sd, p, video, training=True):
+    """The frozen lip-reading encoder of the FiLM model as VideoEncoderModule.forward runs it
+    (DTTNetPlus/modules/video_encoder.py:41-47): Lipreading.forward with extract_feats=True
+    (lipreading/model.py:164-185) = Conv3d stem + BatchNorm3d + ReLU + MaxPool3d (model.py:128-132), then the
+    ShuffleNetV2 1.0x units, the 1x1 conv_last and the 3x3 average pool (lipreading/models/shufflenetv2.py:42-104,
+    118-150).  ``p`` is the prefix of the Lipreading object ("video_encoder.encoder.").
+    video [B,2,T,H,W] -> [B,T,2048] (the input of post_processor)."""
+    B, N, T, H, W = video.shape
+
+    def bn(x, q):
+        return F.batch_norm(x, None if training else sd[q + "running_mean"], None if training else sd[q + "running_var"],
+                            sd[q + "weight"], sd[q + "bias"], training=training, eps=1e-5)
+
+    def pw(x, q, i):                     # 1x1 conv, BN, ReLU at indices i, i+1, i+2 of the Sequential q
+        return torch.relu(bn(F.conv2d(x, sd[f"{q}{i}.weight"]), f"{q}{i + 1}."))
+
+    def dw(x, q, i, stride):             # depthwise 3x3, BN (no activation)
+        w = sd[f"{q}{i}.weight"]
+        return bn(F.conv2d(x, w, None, stride=stride, padding=1, groups=w.shape[0]), f"{q}{i + 1}.")
+
+    x = video.reshape(B * N, 1, T, H, W)
+    x = F.conv3d(x, sd[p + "frontend3D.0.weight"], None, stride=(1, 2, 2), padding=(2, 3, 3))
+    x = torch.relu(bn(x, p + "frontend3D.1."))
+    x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    x = x.transpose(1, 2).reshape(B * N * T, x.shape[1], x.shape[3], x.shape[4])
+    u = 0
+    while f"{p}trunk.0.{u}.banch2.0.weight" in sd:
+        q = f"{p}trunk.0.{u}."
+        if q + "banch1.0.weight" in sd:                       # stride-2 unit: both branches see the whole input
+            a = pw(dw(x, q + "banch1.", 0, 2), q + "banch1.", 2)
+            b = pw(dw(pw(x, q + "banch2.", 0), q + "banch2.", 3, 2), q + "banch2.", 5)
+        else:                                                 # stride-1 unit: first half passes through
+            half = x.shape[1] // 2
+            a = x[:, :half]
+            b = pw(dw(pw(x[:, half:], q + "banch2.", 0), q + "banch2.", 3, 1), q + "banch2.", 5)
+        out = torch.cat((a, b), 1)
+        n, c, h, w = out.shape                                # channel_shuffle(out, 2)
+        x = out.view(n, 2, c // 2, h, w).transpose(1, 2).reshape(n, c, h, w)
+        u += 1
+    x = pw(x, p + "trunk.1.", 0)
+    x = F.avg_pool2d(x, 3).reshape(B, N, T, -1)
+    return x.transpose(1, 2).flatten(-2, -1)
 
 
 def dttnet_vision_forward(sd, spec, phase, audio_length, video_features, fusion_method,

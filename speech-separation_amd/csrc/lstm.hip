@@ -132,117 +132,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmP p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// bf16, H = 256 forward: the recurrent weights (512 KB per direction) cannot live on one CU, so they
-// are re-streamed from L2 every step -- 64 KB per wave.  With register prefetch only ~4 KB per wave is
-// in flight and the step is bound by that stream's latency (measured 17-19 us per step).  Here every
-// wave owns a 16 KB ring in LDS filled by LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction, no
-// VGPRs), 16 instructions deep, so ~128 KB per CU is in flight; the MFMAs read the B fragments from
-// the ring.  The packed weight image is already lane-linear ([64 lanes][8]) as LDS-DMA requires.
-// h is single-buffered (two barriers per step) to leave the LDS to the rings.
 __device__ __forceinline__ float sigm_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-
-__global__ __launch_bounds__(512) void lstm_fwd_stream_kernel(LstmP p) {
-    constexpr int H = 256, NB = 32, LDH = H + 8, KS = 16, G4 = 1024, RING = 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16* hbuf = reinterpret_cast<bf16*>(smem);                       // [NB][LDH]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
-    bf16* ring = hbuf + NB * LDH + wave * RING * 512;                 // this wave's RING fragments of 1 KB
-    const int dir = blockIdx.y, n0 = blockIdx.x * NB;
-    const bf16* xg = reinterpret_cast<const bf16*>(p.xg);
-    const bf16* wp = reinterpret_cast<const bf16*>(p.wp) + (int64_t)dir * G4 * H;
-    bf16* y = reinterpret_cast<bf16*>(p.y);
-    bf16* gates = reinterpret_cast<bf16*>(p.gates);
-    const int jt = wave, j = jt * 32 + lr;
-
-    // fragment (k, g) of this wave's column tile: lane-linear 1 KB in the packed image
-    // (wave-uniform base in SGPRs + lane * 16 bytes: one address VGPR for all 64 fragments)
-    const int jts = __builtin_amdgcn_readfirstlane(wave);
-    const char* wbase = reinterpret_cast<const char*>(wp) + (size_t)jts * KS * 1024;
-    bf16* rings = hbuf + NB * LDH + jts * RING * 512;
-    uint32_t lane16 = lane * 16;
-    auto issue = [&](int k, int g) {
-        // the empty asm keeps the compiler from hoisting all 64 fragment addresses out of the time
-        // loop into 128 VGPRs (it did, and spilled): two VALU adds per DMA instead
-        asm volatile("" : "+v"(lane16));
-        const char* sb = wbase + (size_t)(g * (H / 32) * KS + k) * 1024;          // uniform
-        __builtin_amdgcn_global_load_lds((gptr_t)(sb + lane16), (lptr_t)(rings + (((k & 3) * 4 + g) * 512)), 16, 0, 0);
-    };
-    int rb[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        rb[r] = n < p.N ? (n / p.heads) * p.L * p.heads + (n % p.heads) : -1;
-    }
-    if (p.L > 1) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) issue(k, g);
-    }
-    for (int s = 0; s < p.L; ++s) {
-        const int t = dir ? p.L - 1 - s : s;
-        const int tprev = dir ? t + 1 : t - 1;
-        f32x16_t acc[4];
-        float cprev[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool ok = rb[r] >= 0;
-            const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
-            const bf16* src = xg + (row * 2u + dir) * (uint32_t)G4 + j;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) { const float v = ldf(src + g * H); acc[g][r] = ok ? v : 0.f; }
-            const uint32_t rowp = (uint32_t)(ok && s > 0 ? rb[r] + tprev * p.heads : 0);
-            const float cpl = p.cst[(rowp * 2u + dir) * (uint32_t)H + j];
-            cprev[r] = (ok && s > 0) ? cpl : 0.f;
-        }
-        if (s > 0) {
-            // the ring runs continuously across steps: iteration k consumes the 4 fragments of k-step k
-            // and then refills their slots with k-step k+4 (of the next time step from k = 12 on)
-            const bool more = s + 1 < p.L;
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                const s16x8_t af = MM<bf16>::ldfrag(hbuf + lr * LDH + k * 16 + lh * 8);
-                s16x8_t bq[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const s16x8_t*>(ring + ((k & 3) * 4 + g) * 512 + lane * 8);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (k + 4 < KS || more) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) issue((k + 4) & 15, g);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) MM<bf16>::mma(af, bq[g], acc[g]);
-            }
-        }
-        __syncthreads();                                  // every wave has read h_{t-1}
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const bool ok = rb[r] >= 0;
-            const uint32_t row = (uint32_t)(ok ? rb[r] + t * p.heads : 0);
-            const float ig = sigm_fast(acc[0][r]), fg = sigm_fast(acc[1][r]);
-            const float gg = tanh_fast(acc[2][r]), og = sigm_fast(acc[3][r]);
-            const float c = fg * cprev[r] + ig * gg;
-            const float h = og * tanh_fast(c);
-            stf(hbuf + nl * LDH + j, h);
-            if (ok) {
-                stf(y + (row * 2u + dir) * (uint32_t)H + j, h);
-                p.cst[(row * 2u + dir) * (uint32_t)H + j] = c;
-                if (gates) {
-                    bf16* gd = gates + (row * 2u + dir) * (uint32_t)G4 + j;
-                    stf(gd, ig); stf(gd + H, fg); stf(gd + 2 * H, gg); stf(gd + 3 * H, og);
-                }
-            }
-        }
-        __syncthreads();                                  // h_t complete
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // bf16, H = 256 forward with the input projection fused in: per step
@@ -787,14 +681,6 @@ extern "C" int dtt_lstm_fwd(const void* xg, const void* wp, void* y, void* gates
     LstmP p{xg, wp, y, gates, cst, N, L, heads, H, 32};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     DTT_CHECK(cst != nullptr, "dtt_lstm_fwd: cst scratch is required (cell state round-trips through it)");
-    if (dtype && H == 256) {
-        const size_t sm = (size_t)32 * (256 + 8) * 2 + 8 * 16 * 1024;
-        auto k = lstm_fwd_stream_kernel;
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k, dim3((N + 31) / 32, 2), dim3(512), sm, st, p);
-        DTT_LAUNCH_CHECK();
-        return 0;
-    }
     p.nb = lstm_block_rows(N);
     return dtype ? launch_fwd<bf16, 1>(p, nw, st) : launch_fwd<float, 1>(p, nw, st);
 }

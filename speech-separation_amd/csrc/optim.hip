@@ -51,17 +51,43 @@ __global__ __launch_bounds__(NT) void adamw_sumsq_kernel(const DttOptTensor* __r
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// Deterministic merge of the per-chunk sums of squares into one float (the sharded step all-reduces it).
+__global__ __launch_bounds__(NT) void adamw_merge_kernel(const float* __restrict__ partial, int nchunks, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nchunks; i += NT) acc += partial[i];
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// step_dev (device int32, may be NULL): AdamW step count after this update; when given, the bias corrections are
+// computed here instead of on the host, so that a captured HIP graph replays with the count its caller keeps on
+// the device.  sumsq_dev (may be NULL): total squared gradient norm, already merged (and, for a sharded step,
+// all-reduced) -- replaces the merge of `partial`.  gscale: factor applied to every gradient before anything else
+// (1 / world size when the collective summed instead of averaging); the reported norm is that of the scaled gradients.
 __global__ __launch_bounds__(NT) void adamw_update_kernel(const DttOptTensor* __restrict__ tab, const int2* __restrict__ chunks,
                                                           const float* __restrict__ partial, int nchunks, float max_norm,
                                                           float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                          const int32_t* __restrict__ step_dev,
+                                                          const float* __restrict__ sumsq_dev, float gscale,
                                                           float* __restrict__ norm_out) {
     __shared__ float sh[4];
-    float coef = 1.f;
+    float coef = gscale;
+    if (step_dev) {
+        const double st = (double)step_dev[0];
+        bc1 = (float)(1.0 - pow((double)b1, st));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+    }
     if (max_norm > 0.f) {
-        float acc = 0.f;
-        for (int i = threadIdx.x; i < nchunks; i += NT) acc += partial[i];
-        const float total = sqrtf(block_sum(acc, sh));
-        coef = fminf(1.f, max_norm / (total + 1e-6f));
+        float ss;
+        if (sumsq_dev) ss = sumsq_dev[0];
+        else {
+            float acc = 0.f;
+            for (int i = threadIdx.x; i < nchunks; i += NT) acc += partial[i];
+            ss = block_sum(acc, sh);
+        }
+        const float total = sqrtf(ss) * gscale;
+        coef = gscale * fminf(1.f, max_norm / (total + 1e-6f));
         if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
     }
     const int2 ck = chunks[blockIdx.x];
@@ -113,7 +139,40 @@ extern "C" int dtt_clip_adamw(const DttOptTensor* tab, int ntensors, const int32
     if (max_norm > 0.f) hipLaunchKernelGGL(adamw_sumsq_kernel, dim3(nchunks), dim3(NT), 0, st, tab, ck, partial);
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adamw_update_kernel, dim3(nchunks), dim3(NT), 0, st, tab, ck, partial, nchunks, max_norm, beta1, beta2,
-                       eps, (float)bc1, (float)sqrt(bc2), norm_out);
+                       eps, (float)bc1, (float)sqrt(bc2), (const int32_t*)nullptr, (const float*)nullptr, 1.0f, norm_out);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+// Per-chunk sums of squares of the gradients in `tab`, merged in a fixed order into sumsq_out[0] (2 launches).
+// First half of the sharded step: every rank runs it on its shard of the reduce-scattered
+// gradients, all-reduces the one float, and hands it to dtt_clip_adamw_ex as sumsq_dev.
+extern "C" int dtt_grad_sumsq(const DttOptTensor* tab, int ntensors, const int32_t* chunks, int nchunks, float* partial,
+                              float* sumsq_out, void* stream) {
+    DTT_CHECK(tab && chunks && partial && sumsq_out && ntensors > 0 && nchunks > 0, "dtt_grad_sumsq: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adamw_sumsq_kernel, dim3(nchunks), dim3(NT), 0, st, tab, reinterpret_cast<const int2*>(chunks), partial);
+    hipLaunchKernelGGL(adamw_merge_kernel, dim3(1), dim3(NT), 0, st, partial, nchunks, sumsq_out);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+// dtt_clip_adamw with (a) the step count read from device memory (HIP-graph replay), (b) an externally merged
+// squared norm (sharded step) and (c) a gradient scale folded into the clip coefficient.  step_dev and sumsq_dev
+// may each be NULL: then `step` (>= 1) is used / the norm is computed here from the gradients in `tab`.
+extern "C" int dtt_clip_adamw_ex(const DttOptTensor* tab, int ntensors, const int32_t* chunks, int nchunks, float* partial,
+                                 float max_norm, float beta1, float beta2, float eps, int step, const int32_t* step_dev,
+                                 const float* sumsq_dev, float grad_scale, float* norm_out, void* stream) {
+    DTT_CHECK(tab && chunks && partial && ntensors > 0 && nchunks > 0 && (step_dev || step >= 1) && grad_scale > 0.f,
+              "dtt_clip_adamw_ex: bad arguments");
+    DTT_CHECK(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "dtt_clip_adamw_ex: bad hyper-parameters");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int2* ck = reinterpret_cast<const int2*>(chunks);
+    if (max_norm > 0.f && !sumsq_dev) hipLaunchKernelGGL(adamw_sumsq_kernel, dim3(nchunks), dim3(NT), 0, st, tab, ck, partial);
+    const int sh = step >= 1 ? step : 1;
+    const double bc1 = 1.0 - pow((double)beta1, sh), bc2 = 1.0 - pow((double)beta2, sh);
+    hipLaunchKernelGGL(adamw_update_kernel, dim3(nchunks), dim3(NT), 0, st, tab, ck, partial, nchunks, max_norm, beta1, beta2,
+                       eps, (float)bc1, (float)sqrt(bc2), step_dev, sumsq_dev, grad_scale, norm_out);
     DTT_LAUNCH_CHECK();
     return 0;
 }

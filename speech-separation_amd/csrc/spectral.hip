@@ -110,13 +110,14 @@ __global__ __launch_bounds__(NT) void init_conv_bwd_kernel(const float* __restri
 
 // ---------------- fused out conv (C -> 2S) + mask + polar ----------------
 // x [B][F][T][C]; w [2S][C], bias [2S] f32; mix spec/phase [B][F][T] f32
-// outputs: pspec, pphase [S][B][F][T] f32; Z [S*B][T][ldz] (re at f, im at imoff+f) in T
+// outputs: pspec, pphase [S][B][F][T] f32; Z [S*B][T][ldz] (re at f, im at imoff+f) f32: the reference's
+// polar / istft stay fp32 (complex64) under bf16 autocast, so the spectrum handed to the inverse DFT does too
 template <typename T, int S>
 __global__ __launch_bounds__(NT) void mask_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias,
                                                       const float* __restrict__ mspec,
                                                       const float* __restrict__ mphase, float* __restrict__ pspec,
-                                                      float* __restrict__ pphase, T* __restrict__ Z, int B, int F,
+                                                      float* __restrict__ pphase, float* __restrict__ Z, int B, int F,
                                                       int Tn, int C, int ldz, int imoff) {
     constexpr int EPT = Vec16<T>::N;
     extern __shared__ float sm[];
@@ -163,9 +164,9 @@ __global__ __launch_bounds__(NT) void mask_fwd_kernel(const T* __restrict__ x, c
     if (t0 + tt2 < Tn && f0 + tf2 < F) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            T* zr = Z + (((int64_t)s * B + b) * Tn + t0 + tt2) * ldz;
-            stf(zr + f0 + tf2, tre[(s * 16 + tt2) * 17 + tf2]);
-            stf(zr + imoff + f0 + tf2, tim[(s * 16 + tt2) * 17 + tf2]);
+            float* zr = Z + (((int64_t)s * B + b) * Tn + t0 + tt2) * ldz;
+            zr[f0 + tf2] = tre[(s * 16 + tt2) * 17 + tf2];
+            zr[imoff + f0 + tf2] = tim[(s * 16 + tt2) * 17 + tf2];
         }
     }
 }
@@ -354,7 +355,7 @@ extern "C" int dtt_mask_fwd(const void* x, const float* w, const float* bias, co
               "dtt_mask_fwd: bad shape C=%d S=%d", C, S);
     dim3 grid((F + 15) / 16, (T + 15) / 16, B);
     size_t sm = (size_t)(2 * S * C + 2 * S * 16 * 17) * sizeof(float);
-#define MF(TT, SS) hipLaunchKernelGGL((mask_fwd_kernel<TT, SS>), grid, dim3(NT), sm, ST, (const TT*)x, w, bias, mspec, mphase, pspec, pphase, (TT*)Z, B, F, T, C, ldz, imoff)
+#define MF(TT, SS) hipLaunchKernelGGL((mask_fwd_kernel<TT, SS>), grid, dim3(NT), sm, ST, (const TT*)x, w, bias, mspec, mphase, pspec, pphase, (float*)Z, B, F, T, C, ldz, imoff)
     if (dtype) { if (S == 1) MF(bf16, 1); else if (S == 2) MF(bf16, 2); else MF(bf16, 3); }
     else { if (S == 1) MF(float, 1); else if (S == 2) MF(float, 2); else MF(float, 3); }
 #undef MF

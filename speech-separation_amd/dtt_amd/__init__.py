@@ -10,3 +10,5 @@ from .ops import stft_mag_phase  # noqa: F401
 from .optim import ClipAdamW  # noqa: F401
 from .io import load_reference_checkpoint, save_reference_checkpoint, align_state_dict_keys  # noqa: F401
 from .feeder import collate_on_device  # noqa: F401
+from .graph import GraphedTrainStep  # noqa: F401
+from .dist import GradBucketReducer  # noqa: F401

@@ -52,8 +52,11 @@ class GradBucketReducer:
         if self.world > 1 and broadcast_state:
             self.broadcast_state(module)
         self._hooks = []
-        self._ready = [0] * len(self.buckets)
-        self._launched = [False] * len(self.buckets)
+        self._paused = False
+        self._module = module
+        # RCCL averages inside the collective (ReduceOp.AVG); gloo has no AVG, so sums are scaled in finish()
+        self._avg_in_collective = self.world > 1 and dist.get_backend(process_group) == "nccl"
+        self._reset()
         if self.world > 1:
             for bi, (_, ps, _) in enumerate(self.buckets):
                 for p in ps:
@@ -81,11 +84,47 @@ class GradBucketReducer:
             off += p.numel()
         self.buckets.append((flat, list(ps), views))
 
+    def _reset(self):
+        self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._next = 0                                    # buckets are exchanged strictly in index order
+
+    def pause_hooks(self, paused):
+        """While a HIP graph of forward + backward is being recorded the hooks must not fire (a collective is
+        not part of the recorded step); reduce_grads() exchanges the gradients behind each replay instead."""
+        self._paused = bool(paused)
+
+    def reduce_grads(self, params, grads):
+        """Exchange gradients that live outside ``p.grad`` (the static gradient tensors a replayed HIP graph writes
+        into): gather them into the buckets, all-reduce bucket by bucket, and point ``p.grad`` at the averaged
+        views for the optimizer.  Synchronous with respect to the stream (no overlap with backward: the replay is
+        one launch)."""
+        if self.world == 1:
+            for p, g in zip(params, grads):
+                p.grad = g
+            return
+        by_param = {id(p): g for p, g in zip(params, grads)}
+        for p in self.params:
+            p.grad = by_param.get(id(p))
+        self._reset()
+        self.finish()
+
     def _make_hook(self, bi):
         def hook(_p):
+            if self._paused:
+                return
+            if self._launched[bi]:
+                # a gradient arrived for a bucket that was already exchanged: a second backward without
+                # finish() in between (finish() re-arms the reducer whichever zero_grad the caller uses)
+                raise RuntimeError("GradBucketReducer: backward ran twice without finish(); call reducer.finish() "
+                                   "after every backward (gradient accumulation over several backwards is not "
+                                   "supported)")
             self._ready[bi] += 1
-            if self._ready[bi] == len(self.buckets[bi][1]):
-                self._launch(bi)
+            # every rank issues the collectives in the same (index) order, whatever order its gradients
+            # arrive in: a bucket goes out once it and all buckets before it are complete
+            while self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next][1]):
+                self._launch(self._next)
+                self._next += 1
         return hook
 
     def _launch(self, bi):
@@ -100,21 +139,22 @@ class GradBucketReducer:
         self._launched[bi] = True
         if self._host_staged:
             return                                        # exchanged in finish() through host memory
-        self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        self._pending.append(dist.all_reduce(flat, op=op, group=self.group, async_op=True))
 
     def zero_grad(self):
+        """Same effect as ``optimizer.zero_grad(set_to_none=True)`` / ``model.zero_grad()``: any of the three
+        may be used (the reducer re-arms itself in finish(), not here)."""
         for p in self.params:
             p.grad = None
-        self._ready = [0] * len(self.buckets)
-        self._launched = [False] * len(self.buckets)
 
     def finish(self):
         """Wait for the outstanding all-reduces and turn sums into means."""
         if self.world == 1:
             return
-        for bi in range(len(self.buckets)):               # buckets holding parameters that got no gradient
-            if not self._launched[bi]:
-                self._launch(bi)
+        for bi in range(self._next, len(self.buckets)):   # buckets holding parameters that got no gradient,
+            self._launch(bi)                              # and everything queued behind them, in index order
+        self._next = len(self.buckets)
         for w in self._pending:
             w.wait()
         self._pending = []
@@ -123,8 +163,26 @@ class GradBucketReducer:
                 h = flat.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
                 flat.copy_(h)
-        for flat, _, _ in self.buckets:
-            flat.mul_(1.0 / self.world)
+        if not self._avg_in_collective:
+            torch._foreach_mul_([flat for flat, _, _ in self.buckets], 1.0 / self.world)
+        self._reset()                                     # armed for the next backward
+
+    def sync_buffers(self):
+        """Re-broadcast rank 0's buffers (BatchNorm running statistics of the lip encoder).  torch DDP, which the
+        reference trains under (accelerate, broadcast_buffers=True), does this before every forward; here the
+        training loop calls it where it matters: before evaluation and before saving a checkpoint (and, to
+        reproduce DDP exactly, before each forward)."""
+        if self.world == 1:
+            return
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        with torch.no_grad():
+            for t in self._module.buffers():
+                if self._host_staged:
+                    h = t.detach().cpu()
+                    dist.broadcast(h, src=src, group=self.group)
+                    t.copy_(h)
+                else:
+                    dist.broadcast(t.detach(), src=src, group=self.group)
 
     def remove(self):
         for h in self._hooks:

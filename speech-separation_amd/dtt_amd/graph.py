@@ -1,0 +1,129 @@
+"""The training step as ONE HIP graph.
+
+A DTTNet step is a chain of ~2 400 short kernel launches; issued one by one from
+Python through ctypes the host needs longer to enqueue them than the GPU needs
+to run them (round-1 profile: 68 of 81 ms on the AV cross-attention model).
+MI355X-first answer: record the whole step once -- STFT of mixture and sources,
+model forward, PIT-L1 loss, backward, gradient clip + AdamW -- into a HIP graph
+on torch's capture stream and replay it; the host then issues one launch per
+step.  Everything the kernels touch is torch-owned memory from the graph's
+private pool, the C ABI takes the stream as an argument, and no entry point
+synchronises or allocates, so the capture needs nothing special from the
+library.
+
+What the reference's loop does per step (src/trainer/trainer.py:37-72) maps to:
+
+    step = GraphedTrainStep(model, criterion, optimizer, example_batch)   # records
+    for batch in loader:
+        loss = step(batch)            # copies the batch into the static inputs, replays
+        lr_scheduler.step()           # group["lr"] is re-read before the next replay
+
+With more than one rank the recorded part ends after backward; the gradient
+exchange (GradBucketReducer.reduce_grads) and the optimizer step run behind the
+replay, eagerly.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import DttError
+
+
+def _copy_into(dst, src):
+    """Recursively copy a batch (tensors / lists / dicts of tensors) into its static twin."""
+    if torch.is_tensor(dst):
+        dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _copy_into(dst[k], src[k])
+    elif isinstance(dst, (list, tuple)):
+        for d, s in zip(dst, src):
+            _copy_into(d, s)
+
+
+def _clone_static(x):
+    if torch.is_tensor(x):
+        return x.clone()
+    if isinstance(x, dict):
+        return {k: _clone_static(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clone_static(v) for v in x]
+    return x
+
+
+class GraphedTrainStep:
+    """``batch_fn(inputs) -> batch dict`` turns the static input tensors into the reference's batch dict
+    (collate.py:72-83), e.g. by running the GPU STFT; it is recorded with the rest.  ``inputs`` is any
+    nest of CUDA tensors with the shapes every later batch will have."""
+
+    def __init__(self, model, criterion, optimizer, inputs, batch_fn, reducer=None, warmup=2):
+        if not torch.cuda.is_available():
+            raise DttError("GraphedTrainStep needs an MI355X")
+        self.model, self.criterion, self.opt, self.reducer = model, criterion, optimizer, reducer
+        self.world = reducer.world if reducer is not None else 1
+        if not getattr(optimizer, "capturable", False) and self.world == 1:
+            raise DttError("GraphedTrainStep: build the ClipAdamW with capturable=True")
+        self.static_in = _clone_static(inputs)
+        self.batch_fn = batch_fn
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.graph = torch.cuda.CUDAGraph()
+        self._replays = 0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # eager warm-up on the side stream (torch's recipe):
+            for _ in range(max(1, warmup)):                # library plans, basis tables, MIOpen's find step
+                self._eager_once(step_opt=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if hasattr(optimizer, "prepare"):
+            optimizer.prepare()
+        for p in self.params:
+            p.grad = None
+        ops.reset_zero_arena()                             # zero-filled scratch must be born inside the capture
+        if reducer is not None:
+            reducer.pause_hooks(True)
+        try:
+            with torch.cuda.graph(self.graph):
+                loss = self._fwd_bwd()
+                if self.world == 1:
+                    self.opt.step()
+                self.static_loss = loss.detach()
+        finally:
+            ops.reset_zero_arena()                         # later eager work must not carve from the graph's arena
+            if reducer is not None:
+                reducer.pause_hooks(False)
+        self.graph_grads = [p.grad for p in self.params]   # written in place by every replay: keep them alive
+        if self.world == 1:
+            self.opt.note_recorded_step()                  # recording executed nothing
+
+    def _fwd_bwd(self):
+        batch = self.batch_fn(self.static_in)
+        batch.update(self.model(**batch))
+        batch.update(self.criterion(**batch))
+        batch["loss"].backward()
+        return batch["loss"]
+
+    def _eager_once(self, step_opt):
+        for p in self.params:
+            p.grad = None
+        loss = self._fwd_bwd()
+        if self.reducer is not None:
+            self.reducer.finish()
+        if step_opt:
+            self.opt.step()
+        return loss
+
+    def __call__(self, inputs=None):
+        if inputs is not None:
+            _copy_into(self.static_in, inputs)
+        if self.world == 1:
+            self.opt.refresh_hyper()                       # table upload with the current lr, stream-ordered
+            self.graph.replay()
+            self.opt.note_replayed_step()
+        else:
+            self.graph.replay()
+            self.reducer.reduce_grads(self.params, self.graph_grads)
+            self.opt.step()
+        self._replays += 1
+        return self.static_loss

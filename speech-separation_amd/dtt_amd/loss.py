@@ -10,9 +10,11 @@ from ._lib import DttError
 
 
 def _stack_preds(preds, batch):
-    st = batch.get("_stacked_preds")
+    # the model's own PredList carries the stacked tensors its entries are views of (no side key in the batch)
+    st = getattr(preds, "stacked", None)
     if st is not None and len(preds) == st[0].shape[0] and all(
-            p["audio"].data_ptr() == st[2][i].data_ptr() for i, p in enumerate(preds)):
+            p["audio"]._base is st[2] and p["spectrogram"]._base is st[0] and p["phase"]._base is st[1]
+            and p["audio"].data_ptr() == st[2][i].data_ptr() for i, p in enumerate(preds)):
         return st
     return (torch.stack([p["spectrogram"] for p in preds]), torch.stack([p["phase"] for p in preds]),
             torch.stack([p["audio"] for p in preds]))

@@ -24,6 +24,13 @@ def _nchw(x):
     return x.detach().permute(0, 3, 1, 2).float().contiguous()
 
 
+class PredList(list):
+    """The reference's ``preds`` list (model_dttnet.py:57-68) that also remembers the stacked tensors its
+    entries are views of, so that the fused loss does not have to re-stack them.  It IS a plain list of
+    dicts for every caller; a copy of it (or of its entries) simply loses the shortcut."""
+    stacked = None
+
+
 class _Tap:
     """Optional per-module output recorder (NCHW fp32 copies) for the parity tests."""
     store = None
@@ -259,8 +266,10 @@ class _SeparatorBase(nn.Module):
                                               oc.bias[None, :, None, None]).detach()
         pspec, pphase, audio = ops.MaskISTFT.apply(x, oc.weight, oc.bias, spectrogram, phase, self.n_sources,
                                                    self.n_fft, self.hop_length, int(audio_length))
-        preds = [{"audio": audio[i], "spectrogram": pspec[i], "phase": pphase[i]} for i in range(self.n_sources)]
-        return {"preds": preds, "_stacked_preds": (pspec, pphase, audio)}
+        preds = PredList({"audio": audio[i], "spectrogram": pspec[i], "phase": pphase[i]}
+                         for i in range(self.n_sources))
+        preds.stacked = (pspec, pphase, audio)
+        return {"preds": preds}
 
 
 class DTTNetModel(_SeparatorBase):
@@ -333,24 +342,6 @@ class DTTNetVisionModel(_SeparatorBase):
         return self.postprocess(x, spectrogram, phase, audio_length)
 
 
-class PassThroughVideoEmbedding(nn.Module):
-    """Stand-in for DTTNetPlus' frozen third-party lip-reading front end
-    (src/model/lipreading, 1.4k LoC, checkpoint not shipped: .MISSING_LARGE_BLOBS:1).
-    Holds the trainable ``post_processor`` of VideoEncoderModule
-    (DTTNetPlus/modules/video_encoder.py:34) and applies it to precomputed 2x1024-d
-    lip features; raw video is not supported in this round."""
-
-    def __init__(self, video_embed_dim):
-        super().__init__()
-        self.post_processor = nn.Linear(1024 * 2, video_embed_dim)
-
-    def forward(self, feats):
-        if feats.dim() != 3 or feats.shape[-1] != 2048:
-            raise DttError("DTTNetPlusModel expects precomputed lip features [B, T_v, 2048] "
-                           "(the ShuffleNetV2 front end is not part of this build)")
-        return self.post_processor(feats.float())
-
-
 class DTTNetPlusModel(_SeparatorBase):
     """src/model/DTTNetPlus/model_dttnet.py:10-77: FiLM fusion between the latent TFC-TDF and the IDPs."""
 
@@ -360,18 +351,27 @@ class DTTNetPlusModel(_SeparatorBase):
         super().__init__()
         self.n_sources, self.n_fft, self.hop_length, self.precision = n_sources, n_fft, hop_length, precision
         fc_dim = n_fft // 2 + 1
+        from .video import VideoEncoderModule
         self.encoder = Encoder(fc_dim, 2, g, n_layers, use_checkpoints)
-        self.video_encoder = PassThroughVideoEmbedding(video_embed_dim)
+        self.video_encoder = VideoEncoderModule(video_enc_weights_path, video_embed_dim)
         self.decoder = Decoder(fc_dim, g, n_sources, n_layers, use_checkpoints)
         self.latent = LatentModule((fc_dim + 2 ** n_layers) // 2 ** n_layers, n_heads, g * 2 ** n_layers,
                                    n_idp_layers, video_embed_dim=video_embed_dim)
 
-    def forward(self, spectrogram, phase, audio_length, video, video_encoded=None, **batch):
+    def forward(self, spectrogram, phase, audio_length, video=None, video_encoded=None, video_features=None,
+                **batch):
+        """``video`` [B,2,T_v,88,88] as in the reference (DTTNetPlus/model_dttnet.py:47-52).  Fast paths for
+        callers that cache the frozen encoder's output: ``video_features`` [B,T_v,2048] (ahead of the trainable
+        post_processor) or ``video_encoded`` [B,T_v,D] (behind it)."""
         self._check(spectrogram)
         x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
         if video_encoded is None:
+            if video_features is None:
+                video_features = self.video_encoder.features(video, self.compute_dtype() == torch.bfloat16)
+            elif video_features.dim() != 3 or video_features.shape[-1] != 2048:
+                raise DttError("video_features must be [B, T_v, 2048]")
             with torch.autocast("cuda", enabled=False):
-                video_encoded = self.video_encoder(video)
+                video_encoded = self.video_encoder.post_processor(video_features.float())
         x = self.latent(x, video_encoded)
         x = self.decoder(x, skips)
         return self.postprocess(x, spectrogram, phase, audio_length)

@@ -51,6 +51,12 @@ def _zeros_f32(shape, dev):
     return out
 
 
+def reset_zero_arena():
+    """Forget the current arena (its outstanding views stay valid).  Called around a HIP-graph capture: the
+    zero fill has to be recorded with the step, and eager work afterwards must not carve from graph memory."""
+    _ZARENA.clear()
+
+
 # --------------------------------------------------------------------------- #
 # thin wrappers over the C entry points
 # --------------------------------------------------------------------------- #
@@ -666,17 +672,18 @@ class MaskISTFT(torch.autograd.Function):
         w2 = w.reshape(2 * S, Cc).contiguous()
         pspec = _empty((S, B, Fq, T), F32, dev)
         pphase = _empty((S, B, Fq, T), F32, dev)
-        Z = torch.zeros(S * B, T, ld, dtype=dt, device=dev)
+        # polar + iSTFT stay fp32 in every mode, as the reference's do under bf16 autocast (torch.polar /
+        # torch.istft are complex64): exact-fp32 MFMA GEMM, K ~ 1032 -- under 1 % of the step
+        Z = torch.zeros(S * B, T, ld, dtype=F32, device=dev)
         check(lib().dtt_mask_fwd(ptr(x), ptr(w2), ptr(b), ptr(mspec), ptr(mphase), ptr(pspec), ptr(pphase), ptr(Z),
                                  B, Fq, T, Cc, S, ld, imoff, d, stream_ptr()), "dtt_mask_fwd")
         _, inv = dft_bases(n_fft, dev)
-        invt = inv.to(dt)
         frames = _empty((S * B * T, n_fft), F32, dev)
-        gemm_raw(A=Z, B=invt, C=frames, M=S * B * T, N=n_fft, K=ld, a_ms=ld, a_ks=1, b_ks=1, b_ns=ld, c_ms=n_fft,
-                 c_ns=1, dtype=d, out_f32=1)
+        gemm_raw(A=Z, B=inv, C=frames, M=S * B * T, N=n_fft, K=ld, a_ms=ld, a_ks=1, b_ks=1, b_ns=ld, c_ms=n_fft,
+                 c_ns=1, dtype=0)
         audio = _empty((S, B, length), F32, dev)
         check(lib().dtt_ola_fwd(ptr(frames), ptr(audio), S * B, T, n_fft, hop, length, stream_ptr()), "dtt_ola_fwd")
-        ctx.save_for_backward(x, w2, mspec, mphase, pspec, pphase, invt)
+        ctx.save_for_backward(x, w2, mspec, mphase, pspec, pphase, inv)
         ctx.cfg = (S, n_fft, hop, length, w.shape)
         return pspec, pphase, audio
 
@@ -689,11 +696,11 @@ class MaskISTFT(torch.autograd.Function):
         _, imoff, ld = _ld(n_fft)
         Lp = n_fft + hop * (T - 1)
         daudio = daudio.contiguous().float()
-        gpad = _empty((S * B, Lp), dt, dev)
-        check(lib().dtt_ola_bwd(ptr(daudio), ptr(gpad), S * B, T, n_fft, hop, length, d, stream_ptr()), "dtt_ola_bwd")
+        gpad = _empty((S * B, Lp), F32, dev)
+        check(lib().dtt_ola_bwd(ptr(daudio), ptr(gpad), S * B, T, n_fft, hop, length, 0, stream_ptr()), "dtt_ola_bwd")
         dZ = _empty((S * B, T, ld), F32, dev)
         gemm_raw(A=gpad, B=invt, C=dZ, M=T, N=ld, K=n_fft, batch=S * B, a_ms=hop, a_ks=1, a_bs=Lp, b_ks=ld, b_ns=1,
-                 b_bs=0, c_ms=ld, c_ns=1, c_bs=T * ld, dtype=d, out_f32=1)
+                 b_bs=0, c_ms=ld, c_ns=1, c_bs=T * ld, dtype=0)
         dx = torch.empty_like(x)
         dmask = _empty((B * Fq * T, 2 * S), dt, dev)
         check(lib().dtt_mask_bwd(ptr(w2), ptr(mspec), ptr(mphase), ptr(pspec), ptr(pphase),

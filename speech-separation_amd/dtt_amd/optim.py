@@ -9,7 +9,12 @@ over all gradients, coefficient ``min(1, max_norm / (norm + 1e-6))``); the
 gradients themselves are left unscaled (the clipped values only exist inside
 the update).  fp32 parameters and gradients on one GPU; learning-rate
 schedulers work as with any ``torch.optim.Optimizer`` (``group["lr"]`` is read
-every step)."""
+every step).
+
+``capturable=True`` makes ``step()`` safe to record in a HIP graph (torch.cuda.graph): the step
+count lives on the device and is incremented there, and the table of gradient pointers /
+learning rates is uploaded from ONE pinned buffer, which ``refresh_hyper()`` rewrites before
+each replay (after the scheduler has moved ``group["lr"]``)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -25,16 +30,32 @@ _TAB = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "
 
 
 class ClipAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=None,
+                 capturable=False, grad_scale=1.0):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("ClipAdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_norm = max_norm
+        self.capturable = capturable
+        self.grad_scale = float(grad_scale)      # folded into the clip coefficient (1 / world after a SUM all-reduce)
         self._built = None
         b0 = self.param_groups[0]
         for g in self.param_groups:
             if tuple(g["betas"]) != tuple(b0["betas"]) or g["eps"] != b0["eps"]:
                 raise ValueError("ClipAdamW: betas and eps must be the same in every group")
+
+    def load_state_dict(self, state_dict):
+        """The flat moment buffers and the step counter are rebuilt from the loaded per-parameter state on the
+        next step (without this the loaded ``exp_avg`` / ``exp_avg_sq`` / ``step`` would be ignored once the
+        optimizer has stepped: the flat buffers would keep the old moments)."""
+        super().load_state_dict(state_dict)
+        self._built = None
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.setdefault("capturable", False)
+        self.__dict__.setdefault("grad_scale", 1.0)
+        self._built = None
 
     # ------------------------------------------------------------------ #
     def _build(self):
@@ -58,11 +79,12 @@ class ClipAdamW(torch.optim.Optimizer):
             if "exp_avg" in st:                               # loaded state: carry it over
                 m[off:off + p.numel()].copy_(st["exp_avg"].reshape(-1))
                 v[off:off + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
-                step = int(st["step"]) if step is None else step
+                step = int(float(st["step"])) if step is None else step
             st["exp_avg"] = m[off:off + p.numel()].view_as(p)
             st["exp_avg_sq"] = v[off:off + p.numel()].view_as(p)
         self._step = step or 0
         self._step_t = torch.tensor(float(self._step))       # one tensor shared by every parameter's state
+        self._step_dev = torch.full((1,), self._step, dtype=torch.int32, device=dev) if self.capturable else None
         for p, _ in plist:
             self.state[p]["step"] = self._step_t
         ch = lib().dtt_clip_adamw_chunk()
@@ -97,6 +119,9 @@ class ClipAdamW(torch.optim.Optimizer):
                 loss = closure()
         b = self._built
         if b is None or [p.data_ptr() for p in b["params"]] != b["ptrs"]:
+            if torch.cuda.is_current_stream_capturing():
+                # built inside a capture, the moment buffers would belong to the graph and be re-zeroed by every replay
+                raise DttError("ClipAdamW: call prepare() before recording step() in a HIP graph")
             self._build()
             b = self._built
         grads = [p.grad for p in b["params"]]
@@ -106,23 +131,64 @@ class ClipAdamW(torch.optim.Optimizer):
                                        or not gr.is_cuda):
                     raise DttError("ClipAdamW needs dense contiguous fp32 gradients on the GPU")
             b["checked"] = True
+        gptrs = [0 if gr is None else gr.data_ptr() for gr in grads]
+        if torch.cuda.is_current_stream_capturing():
+            # recording: the gradient addresses are known now (graph memory), the upload itself stays outside the
+            # graph -- refresh_hyper() sends the table ahead of every replay, stream-ordered, with the current lr
+            for t in b["tabs"]:
+                t["g"] = gptrs
+        else:
+            self._upload(gptrs)
+        self._step += 1
+        self._step_t.fill_(float(self._step))
+        if self.capturable:
+            self._step_dev.add_(1)                            # a device op: replayed with the graph
+        g0 = self.param_groups[0]
+        mx = float(self.max_norm) if self.max_norm else 0.0
+        check(lib().dtt_clip_adamw_ex(ptr(b["dev_tab"]), len(b["params"]), ptr(b["chunks"]), b["chunks"].shape[0],
+                                      ptr(b["partial"]), C.c_float(mx), C.c_float(g0["betas"][0]),
+                                      C.c_float(g0["betas"][1]), C.c_float(g0["eps"]), self._step,
+                                      ptr(self._step_dev), None, C.c_float(self.grad_scale), ptr(b["norm"]),
+                                      stream_ptr()), "dtt_clip_adamw_ex")
+        return b["norm"] if mx > 0 else loss
+
+    def prepare(self):
+        """Allocate the flat moment buffers / tables now (must happen outside a graph capture)."""
+        if self._built is None:
+            self._build()
+
+    def _upload(self, gptrs=None):
+        """Table of {p, g, m, v, n, lr, wd} -> device, through one of two pinned copies (the copy issued two
+        uploads ago has been read by the time its buffer is rewritten: one event wait, normally already past)."""
+        b = self._built
         k = b["flip"]
         b["flip"] = 1 - k
         if b["events"][k] is not None:
-            b["events"][k].synchronize()                      # the copy issued two steps ago has read this table
+            b["events"][k].synchronize()
         t = b["tabs"][k]
-        t["g"] = [0 if gr is None else gr.data_ptr() for gr in grads]
+        if gptrs is not None:
+            t["g"] = gptrs
         t["lr"] = np.array([g["lr"] for g in self.param_groups], dtype=np.float32)[b["group_of"]]
         t["wd"] = np.array([g["weight_decay"] for g in self.param_groups], dtype=np.float32)[b["group_of"]]
         b["dev_tab"].copy_(b["hosts"][k], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         b["events"][k] = ev
+
+    def refresh_hyper(self):
+        """capturable mode, ahead of each graph replay (same stream): upload the table with the groups' current
+        lr / weight decay and the gradient addresses noted while recording.  No host synchronisation with the
+        previous replay is needed: the upload is stream-ordered between the two replays."""
+        if not self.capturable or self._built is None:
+            raise DttError("refresh_hyper() is for a capturable ClipAdamW whose step() has been recorded")
+        self._upload()
+
+    def note_recorded_step(self):
+        """Undo the host-side count of a step() that was only recorded into a graph (recording executes nothing)."""
+        self._step -= 1
+        self._step_t.fill_(float(self._step))
+
+    def note_replayed_step(self):
+        """Host-side bookkeeping for a step made by a graph replay (the device count moved by itself)."""
         self._step += 1
         self._step_t.fill_(float(self._step))
-        g0 = self.param_groups[0]
-        mx = float(self.max_norm) if self.max_norm else 0.0
-        check(lib().dtt_clip_adamw(ptr(b["dev_tab"]), len(b["params"]), ptr(b["chunks"]), b["chunks"].shape[0],
-                                   ptr(b["partial"]), C.c_float(mx), C.c_float(g0["betas"][0]), C.c_float(g0["betas"][1]),
-                                   C.c_float(g0["eps"]), self._step, ptr(b["norm"]), stream_ptr()), "dtt_clip_adamw")
-        return b["norm"] if mx > 0 else loss

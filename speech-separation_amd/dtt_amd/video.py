@@ -120,3 +120,116 @@ class VideoEncoder(nn.Module):
         x = x.contiguous(memory_format=torch.channels_last)
         x = self.trunk(x)
         return x.view(B, N, Tn, -1).transpose(2, 3)
+
+
+# --------------------------------------------------------------------------------------------- #
+# Lip-reading front end of the FiLM model (DTTNetPlus): Conv3d stem + ShuffleNetV2 (1.0x) trunk.
+# Reference: src/model/DTTNetPlus/modules/video_encoder.py:8-47 (wrapper, frozen encoder, trainable
+# post_processor), src/model/lipreading/model.py:106-185 (Lipreading with backbone_type="shufflenet",
+# relu_type="relu", extract_feats=True: only frontend3D + trunk run), src/model/lipreading/models/
+# shufflenetv2.py (units and stage widths).  Stock PyTorch-ROCm modules, channels-last, under the same
+# parameter names (``encoder.frontend3D.*``, ``encoder.trunk.0.<unit>.banch1|banch2.*``,
+# ``encoder.trunk.1.*``).  The TCN classification head of the reference's Lipreading object
+# (``encoder.tcn.*``) is never executed with extract_feats=True and is not materialised here:
+# checkpoints are exchanged with strict=False on both sides (model_loader.py:227-239).
+# --------------------------------------------------------------------------------------------- #
+def _pw(ci, co):
+    return [nn.Conv2d(ci, co, 1, 1, 0, bias=False), BatchNorm2d(co), nn.ReLU(inplace=True)]
+
+
+def _dw(c, stride):
+    return [nn.Conv2d(c, c, 3, stride, 1, groups=c, bias=False), BatchNorm2d(c)]
+
+
+class ShuffleUnit(nn.Module):
+    """One ShuffleNetV2 unit (shufflenetv2.py:42-104).  ``banch1`` / ``banch2`` are the reference's
+    (misspelt) attribute names: they are state_dict keys."""
+
+    def __init__(self, inp, oup, stride):
+        super().__init__()
+        half = oup // 2
+        self.down = stride == 2
+        if self.down:
+            self.banch1 = nn.Sequential(*_dw(inp, 2), *_pw(inp, half))
+            self.banch2 = nn.Sequential(*_pw(inp, half), *_dw(half, 2), *_pw(half, half))
+        else:
+            self.banch2 = nn.Sequential(*_pw(half, half), *_dw(half, 1), *_pw(half, half))
+
+    def forward(self, x):
+        if self.down:
+            a, b = self.banch1(x), self.banch2(x)
+        else:
+            a, b = x.chunk(2, dim=1)
+            b = self.banch2(b)
+        # concat + channel shuffle with 2 groups = interleave the two halves channel by channel
+        n, c, h, w = a.shape
+        return torch.stack((a, b), dim=2).reshape(n, 2 * c, h, w).contiguous(memory_format=torch.channels_last)
+
+
+class LipReadingEncoder(nn.Module):
+    """Lipreading(modality="video", backbone_type="shufflenet", width_mult=1.0, relu_type="relu",
+    extract_feats=True): x [B', 1, T, 88, 88] -> [B', T, 1024]."""
+
+    def __init__(self):
+        super().__init__()
+        widths = (24, 116, 232, 464)
+        units, cin = [], widths[0]
+        for cout, rep in zip(widths[1:], (4, 8, 4)):
+            for i in range(rep):
+                units.append(ShuffleUnit(cin, cout, 2 if i == 0 else 1))
+                cin = cout
+        self.trunk = nn.Sequential(nn.Sequential(*units), nn.Sequential(*_pw(cin, 1024)),
+                                   nn.Sequential(nn.AvgPool2d(3)))
+        self.frontend3D = nn.Sequential(
+            nn.Conv3d(1, widths[0], kernel_size=(5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
+            BatchNorm3d(widths[0]), nn.ReLU(True),
+            nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1)))
+        for m in self.modules():                               # model.py:187-211
+            if isinstance(m, (nn.Conv3d, nn.Conv2d)):
+                n = m.out_channels
+                for k in m.kernel_size:
+                    n *= k
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, (nn.BatchNorm3d, nn.BatchNorm2d)):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def forward(self, x, lengths=None):
+        Bp = x.shape[0]
+        x = self.frontend3D(x)
+        Tn = x.shape[2]
+        x = x.transpose(1, 2).reshape(Bp * Tn, x.shape[1], x.shape[3], x.shape[4])
+        x = self.trunk(x.contiguous(memory_format=torch.channels_last))
+        return x.reshape(Bp, Tn, 1024)
+
+
+class VideoEncoderModule(nn.Module):
+    """DTTNetPlus/modules/video_encoder.py:8-47: frozen lip-reading encoder + trainable Linear(2048 -> D).
+    video [B, 2, T, 88, 88] -> [B, T, D].  As in the reference the encoder's parameters are frozen but its
+    BatchNorm layers follow the module's train()/eval() mode."""
+
+    def __init__(self, load_weights_path=None, video_embed_dim=256):
+        super().__init__()
+        self.encoder = LipReadingEncoder()
+        self.load_weights_path = load_weights_path
+        self.post_processor = nn.Linear(1024 * 2, video_embed_dim)
+        if load_weights_path is not None:
+            if not os.path.isfile(load_weights_path):
+                raise FileNotFoundError(f"video encoder weights not found: {load_weights_path}")
+            ck = torch.load(load_weights_path, map_location="cpu", weights_only=True)
+            missing = self.encoder.load_state_dict(ck["model_state_dict"], strict=False)
+            lost = [k for k in missing.missing_keys]
+            if lost:
+                raise KeyError(f"video encoder checkpoint lacks {lost[:3]}...")
+        for p in self.encoder.parameters():
+            p.requires_grad = False
+
+    def features(self, video, bf16=False):
+        """[B, 2, T, H, W] -> [B, T, 2048] lip features (no gradient: frozen)."""
+        B, Cn, T, H, W = video.shape
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            out = self.encoder(video.reshape(B * Cn, 1, T, H, W)).reshape(B, Cn, T, 1024)
+        return out.transpose(1, 2).flatten(-2, -1).float()
+
+    def forward(self, video, bf16=False):
+        return self.post_processor(self.features(video, bf16))

@@ -448,5 +448,127 @@ def main():
         json.dump(MANIFEST, f, indent=0, sort_keys=True)
 
 
+def main_r2():
+    """Round-2 fixtures (own generators: the round-1 fixtures above are not regenerated and stay bit-identical).
+    ``python make_golden.py r2 [lipreading] [film_av] [xattn_g64]``."""
+    torch.set_num_threads(8)
+    _install_reference()
+    import json
+    which = set(sys.argv[2:]) or {"lipreading", "film_av", "xattn_g64"}
+    mpath = os.path.join(HERE, "manifest.json")
+    with open(mpath) as f:
+        MANIFEST.update(json.load(f))
+    from src.model.lipreading.model import Lipreading
+    from src.loss.dttnet_loss import DTTNetLoss
+    from src.loss.pit_loss_wrapper import PITLossWrapper
+    pit = PITLossWrapper(DTTNetLoss())
+    tcn_options = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": True, "width_mult": 1}
+
+    def lipreading():      # exactly the constructor call of DTTNetPlus/modules/video_encoder.py:22-31
+        return Lipreading(modality="video", num_classes=500, tcn_options=tcn_options, densetcn_options={},
+                          backbone_type="shufflenet", relu_type="relu", width_mult=1.0, use_boundary=False,
+                          extract_feats=True)
+
+    if "lipreading" in which:
+        # ---- frozen lip-reading front end alone: eval (running stats) and train (batch stats) mode ----
+        enc = lipreading()
+        sd = enc.state_dict()
+        keep = {k: v for k, v in sd.items() if not k.startswith("tcn.")}
+        MANIFEST["lipreading"] = {k: list(v.shape) for k, v in keep.items()}
+        new = {k: (fill_tensor(k, v.shape, 31).to(v.dtype) if k in keep else v) for k, v in sd.items()}
+        enc.load_state_dict(new)
+        ck = weight_checksum({k: new[k] for k in keep})
+        vid = synth_video(1, 4, seed=32)                      # [1,2,4,88,88]
+        x = vid.reshape(2, 1, 4, 88, 88)
+        enc.eval()
+        with torch.no_grad():
+            y_eval = enc(x, 4).reshape(1, 2, 4, 1024).transpose(1, 2).flatten(-2, -1)
+            enc.train()
+            y_train = enc(x, 4).reshape(1, 2, 4, 1024).transpose(1, 2).flatten(-2, -1)
+        np.savez_compressed(os.path.join(HERE, "lipreading.npz"),
+                            **npify({"y_eval": y_eval, "y_train": y_train, "weight_checksum": ck,
+                                     "n_params_no_tcn": sum(v.numel() for k, v in keep.items()
+                                                            if v.dtype.is_floating_point and "running" not in k)}))
+        print("lipreading", tuple(y_train.shape), float(y_train.abs().mean()))
+
+    if "film_av" in which:
+        # ---- the composed FiLM model through the REAL DTTNetPlusModel.forward with raw video (tiny config) ----
+        from src.model.DTTNetPlus.model_dttnet import DTTNetPlusModel
+        m = DTTNetPlusModel(g=8, n_sources=2, n_layers=3, n_idp_layers=1, n_fft=64, hop_length=16, n_heads=2,
+                            video_embed_dim=24, use_checkpoints=False, video_enc_weights_path=None)
+        sd = m.state_dict()
+        keep = {k: v for k, v in sd.items() if ".encoder.tcn." not in k}
+        MANIFEST["film_av"] = {k: list(v.shape) for k, v in keep.items()}
+        new = {k: (fill_tensor(k, v.shape, 33).to(v.dtype) if k in keep else v) for k, v in sd.items()}
+        m.load_state_dict(new)
+        m.train()
+        batch = make_batch(2, 800, 64, 16, seed=34)
+        vid = synth_video(2, 2, seed=35)                      # T_v = 2 frames for 0.05 s
+        out = m(spectrogram=batch["spectrogram"], phase=batch["phase"], audio_length=800, video=vid)
+        res = pit(audio=batch["audio"], sources=batch["sources"], preds=out["preds"])
+        res["loss"].backward()
+        fx = {"loss": res["loss"].detach(), "batch_permuts": res["batch_permuts"],
+              "weight_checksum": weight_checksum({k: new[k] for k in keep}),
+              "n_trainable": sum(p.numel() for p in m.parameters() if p.requires_grad)}
+        for i, p in enumerate(out["preds"]):
+            for k in ("audio", "spectrogram", "phase"):
+                fx[f"pred{i}.{k}"] = p[k].detach()
+        params = dict(m.named_parameters())
+        for k in ("video_encoder.post_processor.weight", "latent.fusion_block.w_gamma_freq.weight",
+                  "latent.fusion_block.w_beta_channels.bias", "encoder.init_conv.weight",
+                  "latent.idp_modules.0.tc_rnn.blstm.weight_hh_l0", "decoder.out_conv.weight"):
+            fx["grad." + k] = params[k].grad.detach().clone()
+        frozen = [k for k, p in params.items() if k.startswith("video_encoder.encoder.")]
+        assert all(params[k].grad is None for k in frozen)
+        np.savez_compressed(os.path.join(HERE, "film_av.npz"), **npify(fx))
+        print("film_av loss", float(fx["loss"]), "trainable", int(fx["n_trainable"]))
+
+    if "xattn_g64" in which:
+        # ---- cfg5: AV cross-attention 200M (g = 64), 6 s, B = 1, features fed in: scalars / slices ----
+        from src.model.DTTNet.modules.encoder import Encoder
+        from src.model.DTTNet.modules.decoder import Decoder
+        from src.model.DTTNet.modules.latent import LatentModule
+        from src.model.DTTNet import model_dttnet_vision as mdv
+        from src.model.VideoAudioFusions.cross_attention_positional import CrossAttentionPositional
+        from src.metrics.si_snr_i import SiSnrI
+        from src.metrics.base_metric import PIT_wrapper_inference
+        g_, n_fft, hop, L = 64, 1024, 256, 96000
+        m = mdv.DTTNetVisionModel.__new__(mdv.DTTNetVisionModel)
+        torch.nn.Module.__init__(m)
+        m.n_sources, m.n_fft, m.hop_length = 2, n_fft, hop
+        fc = n_fft // 2 + 1
+        m.audio_dim = g_ * 8
+        m.fusion_method = "cross_attention_positional"
+        m.video_encoder = torch.nn.Identity()
+        m.fusion = CrossAttentionPositional(m.audio_dim, 1024, 2)
+        m.encoder = Encoder(fc, 2, g_, 3, False)
+        m.decoder = Decoder(fc, g_, 2, 3, False)
+        m.latent = LatentModule((fc + 8) // 8, 2, g_ * 16, 4)
+        m.channel_compression = torch.nn.Sequential(torch.nn.Conv2d(m.audio_dim * 2, m.audio_dim, 1),
+                                                    torch.nn.InstanceNorm2d(m.audio_dim), torch.nn.GELU())
+        ck = refill(m, seed=41, name="full_xattn_g64")
+        batch = make_batch(1, L, n_fft, hop, seed=42)
+        gg = torch.Generator().manual_seed(43)
+        vf = torch.randn(1, 2, 512, 150, generator=gg).half().float()
+        sl = slice(0, None, 4001)
+        taps_v = ["fusion", "latent.idp_modules.0", "latent", "channel_compression", "decoder.out_conv"]
+        gk = ["fusion.q_audio.weight", "channel_compression.0.weight", "encoder.init_conv.weight",
+              "latent.idp_modules.0.fc_rnn.blstm.weight_ih_l0_reverse", "latent.idp_modules.3.tc_rnn.blstm.weight_hh_l0",
+              "decoder.out_conv.weight"]
+        metrics = {"SiSnrIPITInference": type("M", (), {"__call__": lambda self, **b: PIT_wrapper_inference(SiSnrI(), **b)})()}
+        fx = run_model_case(m, batch, pit, metrics, taps_v, gk, extra_inputs={"video": vf}, full_taps=False, slices=sl)
+        fx["weight_checksum"] = ck
+        fx["in.video_features"] = vf.half()
+        fx["n_params"] = sum(p_.numel() for p_ in m.parameters())
+        np.savez_compressed(os.path.join(HERE, "full_xattn_g64.npz"), **npify(fx))
+        print("full_xattn_g64 loss", float(fx["loss"]), "params", int(fx["n_params"]))
+
+    with open(mpath, "w") as f:
+        json.dump(MANIFEST, f, indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "r2":
+        main_r2()
+    else:
+        main()

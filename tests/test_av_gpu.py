@@ -60,8 +60,23 @@ def test_cross_attention_and_temporal_aligner(dt, tol):
         assert grad_close(p.grad, fx["grad." + k], 2e-4 if dt == torch.float32 else 3e-2,
                           atol=2e-6 if dt == torch.float32 else 2e-3), k
     ta = TemporalAligner(32, 48).to(DEV)
-    ta.load_state_dict(fill_state_dict(load_manifest("temporal_aligner"), 7))
-    assert rel_err(_nchw(ta(_nhwc(fx["a"], dt), fx["v"].to(DEV))), fx["ta_y"]) < tol
+    sdt = fill_state_dict(load_manifest("temporal_aligner"), 7)
+    ta.load_state_dict(sdt)
+    a2 = _nhwc(fx["a"], dt).requires_grad_(True)
+    v2 = fx["v"].to(DEV).requires_grad_(True)
+    yt = ta(a2, v2)
+    assert rel_err(_nchw(yt), fx["ta_y"]) < tol
+    # gradients (a11): against the oracle (whose forward the reference fixture pins) with a seeded upstream gradient
+    gen = torch.Generator().manual_seed(77)
+    gy = torch.randn(fx["ta_y"].shape, generator=gen)
+    sdr = {k: v_.clone().requires_grad_(True) for k, v_ in sdt.items()}
+    ar, vr = fx["a"].clone().requires_grad_(True), fx["v"].clone().requires_grad_(True)
+    oracle.temporal_aligner(sdr, "", ar, vr).backward(gy)
+    yt.backward(_nhwc(gy, dt))
+    assert rel_err(_nchw(a2.grad), ar.grad) < g and rel_err(v2.grad, vr.grad) < g
+    for k, p in ta.named_parameters():
+        assert grad_close(p.grad, sdr[k].grad, 2e-4 if dt == torch.float32 else 3e-2,
+                          atol=2e-6 if dt == torch.float32 else 2e-3), k
 
 
 def test_resnet18_video_encoder():
@@ -74,6 +89,53 @@ def test_resnet18_video_encoder():
     assert rel_err(enc(vid), fx["y_eval"]) < 1e-3
     enc.train()
     assert rel_err(enc(vid), fx["y_train"]) < 1e-3
+
+
+def test_lipreading_front_end():
+    """The frozen ShuffleNetV2 lip-reading encoder of the FiLM model (stock ROCm modules under the reference's
+    parameter names) against the fixture the reference's own Lipreading object produced."""
+    from dtt_amd.video import VideoEncoderModule
+    fx = load_golden("lipreading")
+    enc = VideoEncoderModule(video_embed_dim=24).to(DEV)
+    missing, unexpected = enc.encoder.load_state_dict(fill_state_dict(load_manifest("lipreading"), 31), strict=True)
+    assert all(not p.requires_grad for p in enc.encoder.parameters()) and enc.post_processor.weight.requires_grad
+    vid = synth_video(1, 4, seed=32).to(DEV)
+    enc.eval()
+    assert rel_err(enc.features(vid), fx["y_eval"]) < 1e-3
+    enc.train()
+    assert rel_err(enc.features(vid), fx["y_train"]) < 1e-3
+    assert rel_err(enc.features(vid, bf16=True), fx["y_train"]) < 3e-2
+
+
+def test_film_av_model_fp32_against_reference():
+    """cfg3 drop-in: DTTNetPlusModel.forward(spectrogram, phase, audio_length, video[B,2,T_v,88,88]) against the
+    fixture produced by the reference's REAL DTTNetPlusModel (tiny config, train mode): predictions, PIT loss,
+    permutation (bit-exact), gradients; the lip encoder stays frozen."""
+    import dtt_amd
+    fx = load_golden("film_av")
+    model = dtt_amd.DTTNetPlusModel(g=8, n_sources=2, n_layers=3, n_idp_layers=1, n_fft=64, hop_length=16, n_heads=2,
+                                    video_embed_dim=24, precision="fp32").to(DEV)
+    man = load_manifest("film_av")
+    assert set(man) == set(model.state_dict().keys())          # reference keys minus the unused encoder.tcn.* head
+    model.load_state_dict(fill_state_dict(man, 33))
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == int(fx["n_trainable"])
+    model.train()
+    b = to_dev(make_batch(2, 800, 64, 16, seed=34), DEV)
+    out = model(video=synth_video(2, 2, seed=35).to(DEV), **b)
+    assert set(out.keys()) == {"preds"}
+    for i in range(2):
+        for k in ("audio", "spectrogram", "phase"):
+            e = rel_err(out["preds"][i][k], fx[f"pred{i}.{k}"])
+            assert e < 5e-4, (i, k, e)
+    b.update(out)
+    res = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())(**b)
+    assert torch.equal(res["batch_permuts"].cpu(), fx["batch_permuts"])
+    assert rel_err(res["loss"], fx["loss"]) < 2e-5
+    res["loss"].backward()
+    params = dict(model.named_parameters())
+    for k in [k[5:] for k in fx if k.startswith("grad.")]:
+        assert rel_err(params[k].grad, fx["grad." + k]) < 5e-3, k
+    assert all(p.grad is None for n, p in params.items() if n.startswith("video_encoder.encoder."))
 
 
 def test_tiny_xattn_model_fp32():
@@ -119,9 +181,9 @@ def test_tiny_film_model_fp32_vs_oracle():
     g = torch.Generator().manual_seed(31)
     model = dtt_amd.DTTNetPlusModel(g=8, n_sources=2, n_layers=3, n_idp_layers=2, n_fft=64, hop_length=16,
                                     n_heads=2, video_embed_dim=24, precision="fp32").to(DEV)
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.startswith("video_encoder.encoder.")}
     sd = fill_state_dict(shapes, 17)
-    model.load_state_dict(sd)
+    model.load_state_dict(sd, strict=False)
     cpu = make_batch(2, 800, 64, 16, seed=19)
     feats = torch.randn(2, 5, 2048, generator=g) * 0.1
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
@@ -134,7 +196,7 @@ def test_tiny_film_model_fp32_vs_oracle():
     R = [{k: torch.randn(ref["preds"][i][k].shape, generator=g) for k in ("audio", "spectrogram", "phase")} for i in range(2)]
     sum((ref["preds"][i][k] * R[i][k]).sum() for i in range(2) for k in R[i]).backward()
     b = to_dev(cpu, DEV)
-    out = model(video=feats.to(DEV), **b)
+    out = model(video_features=feats.to(DEV), **b)
     for i in range(2):
         for k in ("audio", "spectrogram", "phase"):
             e = rel_err(out["preds"][i][k], ref["preds"][i][k])
@@ -145,6 +207,8 @@ def test_tiny_film_model_fp32_vs_oracle():
     assert rel_err(res["loss"], rl["loss"]) < 1e-5
     sum((out["preds"][i][k] * R[i][k].to(DEV)).sum() for i in range(2) for k in R[i]).backward()
     for k, p_ in model.named_parameters():
+        if not p_.requires_grad:
+            continue                                          # the frozen lip-reading encoder
         gr = sdr[k].grad
         if k.endswith(".bias") and float(p_.grad.abs().max()) == 0.0:
             # a conv bias ahead of an affine-free InstanceNorm: exactly 0 here, rounding noise in the oracle

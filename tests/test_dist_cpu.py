@@ -9,6 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NSTEPS = 4
 
 
 def _worker(rank, world, port, q):
@@ -25,15 +26,38 @@ def _worker(rank, world, port, q):
     assert len(red.buckets) >= 2
     assert int(net.steps_seen) == 7
     g = torch.Generator().manual_seed(100)
-    x_all = torch.randn(2, 2 * world, 12, generator=g)
+    x_all = torch.randn(NSTEPS, 2 * world, 12, generator=g)
     out = []
-    for step in range(2):
-        red.zero_grad()
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)        # the reference's loop calls optimizer.zero_grad()
+    for step in range(NSTEPS):
+        # every way a training loop may clear gradients must leave the reducer armed (it re-arms in finish())
+        if step == 0:
+            red.zero_grad()
+        elif step == 1:
+            opt.zero_grad()                                # trainer.py:42
+        elif step == 2:
+            net.zero_grad(set_to_none=False)               # gradients stay views of the buckets, zeroed in place
+        else:
+            net.zero_grad()
         x = x_all[step, rank * 2:(rank + 1) * 2]
         y = net[:5](x) if step == 1 else net(x)
         y.pow(2).mean().backward()
         red.finish()
-        out.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone())
+        out.append(torch.cat([torch.zeros_like(p).reshape(-1) if p.grad is None else p.grad.reshape(-1)
+                              for p in net.parameters()]).clone())
+    # a second backward without finish() must be refused, not silently exchanged wrong
+    net.zero_grad()
+    net(x_all[0, rank * 2:(rank + 1) * 2]).pow(2).mean().backward()
+    try:
+        net(x_all[0, rank * 2:(rank + 1) * 2]).pow(2).mean().backward()
+        refused = False
+    except RuntimeError as e:
+        refused = "finish()" in str(e)
+    red.finish()
+    assert refused
+    net.steps_seen += rank                                 # buffers drift per rank; sync_buffers restores rank 0's
+    red.sync_buffers()
+    assert int(net.steps_seen) == 7
     if rank == 0:
         q.put([o.numpy() for o in out])
     dist.destroy_process_group()
@@ -54,8 +78,8 @@ def test_bucket_reducer_matches_single_process_mean():
     net = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, 40), torch.nn.Tanh(),
                               torch.nn.Linear(40, 3), torch.nn.Linear(3, 3))
     g = torch.Generator().manual_seed(100)
-    x_all = torch.randn(2, 2 * world, 12, generator=g)
-    for step in range(2):
+    x_all = torch.randn(NSTEPS, 2 * world, 12, generator=g)
+    for step in range(NSTEPS):
         net.zero_grad(set_to_none=False)
         for p in net.parameters():
             if p.grad is None:

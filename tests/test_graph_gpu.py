@@ -1,0 +1,76 @@
+"""The training step recorded into ONE HIP graph (dtt_amd.GraphedTrainStep) must follow the eagerly issued
+step: same losses, same weights after several steps with changing inputs and a moving learning rate."""
+import pytest
+import torch
+
+from oracle.fill import fill_state_dict, synth_sources
+from conftest import load_manifest
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(capturable):
+    import dtt_amd
+    model = dtt_amd.DTTNetModel(g=8, n_sources=2, n_layers=3, n_idp_layers=1, n_fft=64, hop_length=16, n_heads=2,
+                                precision="fp32").to(DEV)
+    model.load_state_dict(fill_state_dict(load_manifest("tiny_audio"), 1))
+    decay = [p for n, p in model.named_parameters() if "bias" not in n]
+    no_decay = [p for n, p in model.named_parameters() if "bias" in n]
+    opt = dtt_amd.ClipAdamW([{"params": decay, "weight_decay": 1e-2}, {"params": no_decay, "weight_decay": 0.0}],
+                            lr=1e-3, max_norm=2.0, capturable=capturable)
+    return model, opt, dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())
+
+
+def _batch_fn(inp):
+    import dtt_amd
+    s1, s2 = inp["s1"], inp["s2"]
+    mix = s1 + s2
+    spec, phase = dtt_amd.stft_mag_phase(mix, 64, 16)
+    sources = []
+    for s in (s1, s2):
+        sp, ph = dtt_amd.stft_mag_phase(s, 64, 16)
+        sources.append({"audio": s, "spectrogram": sp, "phase": ph})
+    return {"audio": mix, "spectrogram": spec, "phase": phase, "sources": sources, "audio_length": 800}
+
+
+def test_graphed_step_follows_eager_step():
+    import dtt_amd
+    inputs = []
+    for i in range(4):
+        s1, s2 = synth_sources(2, 800, seed=60 + i)
+        inputs.append({"s1": s1.to(DEV), "s2": s2.to(DEV)})
+    lrs = [1e-3, 3e-3, 2e-3, 5e-4]
+
+    m_e, o_e, crit = _setup(False)
+    losses_e = []
+    for inp, lr in zip(inputs, lrs):
+        for grp in o_e.param_groups:
+            grp["lr"] = lr
+        o_e.zero_grad()
+        b = _batch_fn(inp)
+        b.update(m_e(**b))
+        b.update(crit(**b))
+        b["loss"].backward()
+        o_e.step()
+        losses_e.append(float(b["loss"].detach()))
+
+    m_g, o_g, crit = _setup(True)
+    step = dtt_amd.GraphedTrainStep(m_g, crit, o_g, inputs[0], _batch_fn, warmup=1)
+    losses_g = []
+    for inp, lr in zip(inputs, lrs):
+        for grp in o_g.param_groups:
+            grp["lr"] = lr
+        losses_g.append(float(step(inp)))
+    # eager work after the capture must not touch graph memory (fresh zero arena): one more eager forward/backward
+    b = _batch_fn(inputs[1])
+    b.update(m_g(**b))
+    b.update(crit(**b))
+    b["loss"].backward()
+    torch.cuda.synchronize()
+    for a, b_ in zip(losses_e, losses_g):
+        assert abs(a - b_) <= 2e-4 * abs(a), (losses_e, losses_g)
+    for (k, p), q in zip(m_e.named_parameters(), m_g.parameters()):
+        d = float((p - q).detach().abs().max())
+        assert d <= 2e-4 * float(p.detach().abs().max()) + 1e-6, (k, d)
+    assert float(o_g.state_dict()["state"][0]["step"]) == 4.0

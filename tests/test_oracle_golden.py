@@ -221,6 +221,39 @@ def test_resnet18_video_encoder():
     assert rel_err(oracle.resnet18_video_encoder(sd, "", vid, training=False), fx["y_eval"]) < 1e-4
 
 
+def test_lipreading_front_end_and_film_av_model():
+    """cfg3: the frozen ShuffleNetV2 lip-reading front end (fixture from the reference's own Lipreading object,
+    train and eval BatchNorm modes) and the composed FiLM model through the reference's REAL
+    DTTNetPlusModel.forward with raw video [B,2,T_v,88,88]."""
+    import torch.nn.functional as F
+    fx = load_golden("lipreading")
+    sd = _sd("lipreading", 31)
+    assert abs(weight_checksum(sd) / float(fx["weight_checksum"]) - 1) < 1e-9
+    vid = synth_video(1, 4, seed=32)
+    assert rel_err(oracle.lipreading_video_features(sd, "", vid, training=True), fx["y_train"]) < 2e-5
+    assert rel_err(oracle.lipreading_video_features(sd, "", vid, training=False), fx["y_eval"]) < 2e-5
+    fx = load_golden("film_av")
+    sd = _sd("film_av", 33)
+    assert abs(weight_checksum(sd) / float(fx["weight_checksum"]) - 1) < 1e-9
+    gkeys = [k[5:] for k in fx if k.startswith("grad.")]
+    _grads_of(sd, gkeys)
+    b = make_batch(2, 800, 64, 16, seed=34)
+    with torch.no_grad():
+        feats = oracle.lipreading_video_features(sd, "video_encoder.encoder.", synth_video(2, 2, seed=35), training=True)
+    venc = F.linear(feats, sd["video_encoder.post_processor.weight"], sd["video_encoder.post_processor.bias"])
+    out = oracle.dttnet_film_forward(sd, b["spectrogram"], b["phase"], 800, venc, n_fft=64, hop=16)
+    for i in range(2):
+        for k in ("audio", "spectrogram", "phase"):
+            assert rel_err(out["preds"][i][k], fx[f"pred{i}.{k}"]) < 3e-4, (i, k)   # end-to-end fp32 envelope
+    r = oracle.pit_loss(b["audio"], b["sources"], out["preds"])
+    assert torch.equal(r["batch_permuts"], fx["batch_permuts"])
+    assert rel_err(r["loss"], fx["loss"]) < TOL
+    r["loss"].backward()
+    for k in gkeys:
+        e = rel_err(sd[k].grad, fx["grad." + k])
+        assert e < 2e-3, (k, e)    # sign() gradients of the L1 loss, see tiny_audio test
+
+
 def test_tiny_xattn_model():
     fx = load_golden("tiny_xattn")
     sd = _sd("tiny_xattn", 10)

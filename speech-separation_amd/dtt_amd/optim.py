@@ -50,6 +50,11 @@ class ClipAdamW(torch.optim.Optimizer):
         optimizer has stepped: the flat buffers would keep the old moments)."""
         super().load_state_dict(state_dict)
         self._built = None
+        # rebuild NOW: torch hands loaded tensors over without copying them when device and dtype already match,
+        # so the loaded moments may alias the flat buffers of the optimizer that produced the state_dict
+        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if ps and all(p.is_cuda for p in ps):
+            self._build()
 
     def __setstate__(self, state):
         super().__setstate__(state)

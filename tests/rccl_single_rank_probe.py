@@ -1,5 +1,7 @@
 """RCCL path of GradBucketReducer on one GPU: a one-rank "nccl" group, the reducer told the world is 2 so that its
-hooks, asynchronous bucket all-reduces and waits all run; sums over one rank are identities, so grads come out halved."""
+hooks, asynchronous bucket all-reduces (ReduceOp.AVG inside the collective) and waits all run; an average over one
+rank is the identity, so the gradients must come out unchanged and one collective per bucket must have been issued.
+Second leg: the gradients of a replayed HIP graph exchanged through reduce_grads()."""
 import os, sys, torch
 import torch.distributed as dist
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speech-separation_amd"))
@@ -15,6 +17,12 @@ dist.get_world_size = lambda group=None: 2
 red = ddist.GradBucketReducer(model, bucket_bytes=64 << 10)
 dist.get_world_size = real
 print("buckets", len(red.buckets), "host_staged", red._host_staged, flush=True)
+calls = []
+real_ar = dist.all_reduce
+def counting_all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+    calls.append(op)
+    return real_ar(t, op=op, group=group, async_op=async_op)
+dist.all_reduce = counting_all_reduce
 x = torch.randn(2, 800, device="cuda")
 def run(reducer):
     spec, phase = dtt_amd.stft_mag_phase(x, 64, 16)
@@ -29,8 +37,35 @@ def run(reducer):
 g_red = run(red)
 red.remove()
 g_ref = run(None)
-worst = max(float((a - 0.5 * b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(g_red, g_ref))
-print("worst rel deviation from half the plain gradient:", worst, flush=True)
+worst = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(g_red, g_ref))
+print("worst rel deviation from the plain gradient:", worst, "collectives", len(calls), flush=True)
 assert worst < 1e-5
+assert len(calls) == len(red.buckets) and all(op == dist.ReduceOp.AVG for op in calls)
+# ---- second leg: forward + backward as a replayed HIP graph, gradients exchanged behind the replay ----
+dist.get_world_size = lambda group=None: 2
+red2 = ddist.GradBucketReducer(model, bucket_bytes=64 << 10)
+dist.get_world_size = real
+crit = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())
+opt = dtt_amd.ClipAdamW(model.parameters(), lr=1e-3, max_norm=2.0)
+s1, s2 = torch.randn(2, 800, device="cuda") * 0.1, torch.randn(2, 800, device="cuda") * 0.1
+def batch_fn(inp):
+    mix = inp["s1"] + inp["s2"]
+    spec, phase = dtt_amd.stft_mag_phase(mix, 64, 16)
+    srcs = []
+    for s in (inp["s1"], inp["s2"]):
+        sp, ph = dtt_amd.stft_mag_phase(s, 64, 16)
+        srcs.append({"audio": s, "spectrogram": sp, "phase": ph})
+    return {"audio": mix, "spectrogram": spec, "phase": phase, "sources": srcs, "audio_length": 800}
+w_before = [p.detach().clone() for p in model.parameters()]
+del calls[:]
+step = dtt_amd.GraphedTrainStep(model, crit, opt, {"s1": s1, "s2": s2}, batch_fn, reducer=red2, warmup=1)
+n_warm = len(calls)
+l1 = float(step({"s1": s1, "s2": s2}))
+l2 = float(step({"s1": s1, "s2": s2}))
+torch.cuda.synchronize()
+print("graph leg: losses", l1, l2, "collectives per step", (len(calls) - n_warm) // 2, flush=True)
+assert len(calls) - n_warm == 2 * len(red2.buckets)
+assert l2 < l1 and all(torch.isfinite(p).all() for p in model.parameters())
+assert any(float((p.detach() - w).abs().max()) > 0 for p, w in zip(model.parameters(), w_before))
 dist.destroy_process_group()
 print("rccl single-rank probe ok")

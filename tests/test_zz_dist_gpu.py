@@ -107,7 +107,7 @@ def test_two_ranks_match_one_process_over_the_whole_batch():
 def test_reducer_async_path_over_rccl_one_rank():
     """The RCCL ("nccl") leg of GradBucketReducer -- asynchronous bucket all-reduces issued from the grad hooks, waits in
     finish() -- on the one GPU a test box has: a one-rank group with the reducer told the world is 2, so every
-    collective runs (sums over one rank are identities) and the gradients must come out exactly halved.  Own process:
+    collective runs (ReduceOp.AVG over one rank is the identity: gradients unchanged, one collective per bucket).  Own process:
     the process group must not leak into the other tests."""
     import subprocess
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_single_rank_probe.py")

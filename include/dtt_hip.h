@@ -185,6 +185,17 @@ int dtt_l1_bwd(const float* pred, const float* const* src, const int64_t* permut
 int dtt_sisnr(const float* est, const float* const* src, float* partial, float* alpha, float* out, int E, int S,
               int B, int64_t L, int nchunks, float eps, void* stream);
 
+/* dtt_sisnr for callers that cannot allocate.  NO counterpart in the reference: it exists for callers of this
+ * library that may not call hipMalloc (code under HIP-graph capture, tight serving loops, harnesses that forbid
+ * allocation).  Same four launches and the same result, bit for bit, as dtt_sisnr with
+ * nchunks = max(1, min(32, L / 2048)); the chunk partials and projection coefficients live in a static device
+ * array of dtt_sisnr_noalloc_max_floats() floats (1 MiB, one copy per GPU for the life of the process) instead
+ * of caller-provided scratch.  Sizes with E*S*B*(2*nchunks+1) floats beyond that are refused with an error.
+ * The call allocates and frees nothing.  Calls that overlap on one GPU (different streams) race on the array. */
+int dtt_sisnr_noalloc(const float* est, const float* const* src, float* out, int E, int S, int B, int64_t L,
+                      float eps, void* stream);
+int dtt_sisnr_noalloc_max_floats(void);
+
 /* ---------------------------------------------------------------------------
  * Elementwise: op 0 add / 1 mul (decoder.py:43 skip multiply); FiLM apply
  * (block_fusion.py:30-37; gbc [B][T][2C] = gamma_c|beta_c, gbf [B][T][2F]);

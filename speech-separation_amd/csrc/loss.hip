@@ -3,6 +3,7 @@
 // two-stage and deterministic.
 // Reference: src/loss/dttnet_loss.py:28-34, src/loss/pit_loss_wrapper.py:41-71,
 // src/loss/dttnet_loss_wrapper.py:41-62, src/metrics/si_snr.py:26-34.
+#include <mutex>
 #include "common.h"
 #include "../../include/dtt_hip.h"
 
@@ -231,6 +232,81 @@ extern "C" int dtt_sisnr(const float* est, const float* const* src, float* parti
     hipLaunchKernelGGL(sisnr_finalize<0>, dim3((n + 127) / 128), dim3(128), 0, ST, partial, n, nchunks, eps, alpha);
     hipLaunchKernelGGL(sisnr_kernel<1>, grid, dim3(NT), 0, ST, est, sp, E, S, B, L, chunk, alpha, partial);
     hipLaunchKernelGGL(sisnr_finalize<1>, dim3((n + 127) / 128), dim3(128), 0, ST, partial, n, nchunks, eps, out);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dtt_sisnr for callers that cannot allocate (HIP-graph capture regions, tight serving loops, harnesses
+// that forbid hipMalloc): the chunk partials and the projection coefficients live in a file-scope device
+// array instead of caller-provided scratch.  No counterpart in the reference.
+//
+// Each GPU holds its own copy of the array at its own address for the life of the process (1 MiB).
+// The array's NAME is only a host-side stand-in: the device address is looked up once per device with
+// hipGetSymbolAddress (that device current) and kept; kernels and every other use take that pointer.
+// The kernels overwrite every word they later read, so nothing has to be cleared between calls; calls
+// that overlap on one GPU (two streams) race on the array.
+namespace {
+constexpr int SISNR_SCRATCH_FLOATS = 256 * 1024;
+static __device__ __align__(256) float g_sisnr_scratch[SISNR_SCRATCH_FLOATS];
+
+constexpr int MAX_DEVICES = 64;
+float* g_scratch_ptr[MAX_DEVICES];                       // per device: 0 until looked up
+std::mutex g_scratch_mu;
+
+// Device pointer of this device's copy of the scratch array (looked up once per device, that device current).
+int sisnr_scratch_for_stream(hipStream_t st, float** out) {
+    int dev = -1;
+    if (st == nullptr || hipStreamGetDevice(st, &dev) != hipSuccess) {
+        DTT_CHECK(hipGetDevice(&dev) == hipSuccess, "dtt_sisnr_noalloc: no current device");
+    }
+    DTT_CHECK(dev >= 0 && dev < MAX_DEVICES, "dtt_sisnr_noalloc: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        int cur = -1;
+        DTT_CHECK(hipGetDevice(&cur) == hipSuccess, "dtt_sisnr_noalloc: no current device");
+        if (cur != dev) DTT_CHECK(hipSetDevice(dev) == hipSuccess, "dtt_sisnr_noalloc: cannot select device %d", dev);
+        float* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_sisnr_scratch));
+        if (cur != dev) (void)hipSetDevice(cur);
+        DTT_CHECK(e == hipSuccess && p != nullptr, "dtt_sisnr_noalloc: hipGetSymbolAddress failed on device %d: %s", dev,
+                  hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" int dtt_sisnr_noalloc_max_floats(void) { return SISNR_SCRATCH_FLOATS; }
+
+// Same result as dtt_sisnr called with nchunks = max(1, min(32, L / 2048)) (what dtt_amd's metrics use),
+// bit for bit: the same four launches, scratch = this GPU's static array.  E * S * B * (2 * nchunks + 1)
+// floats must fit dtt_sisnr_noalloc_max_floats().
+extern "C" int dtt_sisnr_noalloc(const float* est, const float* const* src, float* out, int E, int S, int B, int64_t L,
+                                 float eps, void* stream) {
+    DTT_CHECK(est && src && out, "dtt_sisnr_noalloc: null buffer");
+    DTT_CHECK(S >= 1 && S <= MAXS && E >= 1 && B > 0 && L > 0 && E * S <= 65535, "dtt_sisnr_noalloc: bad shape");
+    int nchunks = (int)(L / 2048);
+    nchunks = nchunks < 1 ? 1 : (nchunks > 32 ? 32 : nchunks);
+    const int64_t n = (int64_t)E * S * B;
+    const int64_t need = n * (2 * nchunks + 1);
+    DTT_CHECK(need <= SISNR_SCRATCH_FLOATS,
+              "dtt_sisnr_noalloc: E*S*B*(2*nchunks+1) = %lld floats of scratch exceed the static %d (use dtt_sisnr with "
+              "caller-provided scratch for this size)", (long long)need, SISNR_SCRATCH_FLOATS);
+    float* scratch = nullptr;
+    if (int rc = sisnr_scratch_for_stream(ST, &scratch)) return rc;
+    float* partial = scratch;                              // [n][nchunks][2]
+    float* alpha = scratch + n * 2 * nchunks;              // [n]
+    SrcPtrs sp{};
+    for (int s = 0; s < S; ++s) sp.p[s] = src[s];
+    const int64_t chunk = (L + nchunks - 1) / nchunks;
+    dim3 grid(nchunks, B, E * S);
+    const int ni = (int)n;
+    hipLaunchKernelGGL(sisnr_kernel<0>, grid, dim3(NT), 0, ST, est, sp, E, S, B, L, chunk, (const float*)nullptr, partial);
+    hipLaunchKernelGGL(sisnr_finalize<0>, dim3((ni + 127) / 128), dim3(128), 0, ST, partial, ni, nchunks, eps, alpha);
+    hipLaunchKernelGGL(sisnr_kernel<1>, grid, dim3(NT), 0, ST, est, sp, E, S, B, L, chunk, alpha, partial);
+    hipLaunchKernelGGL(sisnr_finalize<1>, dim3((ni + 127) / 128), dim3(128), 0, ST, partial, ni, nchunks, eps, out);
     DTT_LAUNCH_CHECK();
     return 0;
 }

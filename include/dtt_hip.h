@@ -145,6 +145,25 @@ int dtt_lstm_fwd(const void* xg, const void* wp, void* y, void* gates, float* cs
 int dtt_lstm_bwd(const void* dy, const void* gates, const float* cst, const void* wpt, void* dG, int N, int L,
                  int heads, int H, int dtype, void* stream);
 
+/* Weight-stationary form of the same recurrence (nn.LSTM forward / backward, latent.py:87-92) for the wide
+ * latents of the audio-visual models: the 4H gate columns of a direction are split over G workgroups that keep
+ * their rows of W_hh resident in LDS for all L steps; h_t (forward) / dG_t (backward) is exchanged between the
+ * CUs of a sequence group once per step through the output buffer (write-through stores + one counter per
+ * group).  The grid (2 * S * G workgroups) is sized to the CU count: all workgroups must be co-resident.
+ *   dtt_lstm_cluster_geometry: U hidden units per workgroup, G = H / U, S sequence groups; returns 1 when the
+ *     shape is not covered (use dtt_lstm_fwd / dtt_lstm_bwd).
+ *   xg [rows][2][4H] as for dtt_lstm_fwd; whh [2][4H][H] (PyTorch layout, dtype); whhT [2][H][4H] = its transpose;
+ *   y [rows][2H]; gates_blk [2][NT][L][4][H][2][16] (dtype), cst_blk [2][NT][L][H][2][16] fp32, NT = ceil(N/32);
+ *   dG [rows][2][4H]; dcbuf [2][NT][H][32] fp32 scratch; dbias [2][4H] fp32 zeroed by the caller (or NULL);
+ *   sync: dtt_lstm_cluster_sync_words(S) uint32 of scratch (zeroed by the call). */
+int dtt_lstm_cluster_geometry(int N, int H, int dtype, int* U, int* G, int* S);
+int dtt_lstm_cluster_sync_words(int S);
+int dtt_lstm_cluster_fwd(const void* xg, const void* whh, void* y, void* gates_blk, float* cst_blk, unsigned* sync,
+                         int N, int L, int heads, int H, int dtype, void* stream);
+int dtt_lstm_cluster_bwd(const void* dy, const void* gates_blk, const float* cst_blk, const void* whhT, void* dG,
+                         float* dcbuf, float* dbias, unsigned* sync, int N, int L, int heads, int H, int dtype,
+                         void* stream);
+
 /* ---------------------------------------------------------------------------
  * STFT / iSTFT glue (base_dataset.py:154-167; model_dttnet.py:77-85), the 1x1
  * input conv (encoder.py:26-27) and the fused out conv + mask + torch.polar

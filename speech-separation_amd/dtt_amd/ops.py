@@ -428,6 +428,19 @@ def _unblock(t, W, N, L, heads):
     return v.contiguous()
 
 
+def _cluster_geometry(N, H, d):
+    """(U, G, S) of the weight-stationary cluster kernels for this shape on this GPU, or None."""
+    U, G, S = C.c_int(0), C.c_int(0), C.c_int(0)
+    if lib().dtt_lstm_cluster_geometry(N, H, d, C.byref(U), C.byref(G), C.byref(S)) != 0:
+        return None
+    return U.value, G.value, S.value
+
+
+def _lstm_mode():
+    """DTT_LSTM = auto | cluster | stream (A/B switch between the recurrent kernel families)."""
+    return os.environ.get("DTT_LSTM", "auto")
+
+
 class DualPathRNN(torch.autograd.Function):
     """One TC_FC_RNN over the time axis (along_f=False) or the frequency axis
     (along_f=True) of x [B,F,T,C], heads folded into the sequence batch.
@@ -457,14 +470,29 @@ class DualPathRNN(torch.autograd.Function):
                                C.c_float(1e-5), d, stream_ptr()), "dtt_gn_fwd")
         wih = torch.cat([w_ih, w_ih_r], 0).to(dt).contiguous()                 # [8H][Cp]
         bsum = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r]).contiguous()
-        wp = torch.stack([_pack_whh_fwd(w_hh, dt), _pack_whh_fwd(w_hh_r, dt)]).contiguous()
         y = _empty((R, 2 * H), dt, dev)
         need = any(ctx.needs_input_grad)
         N = nslab * heads
-        blocked = dt == torch.bfloat16 and H == 256 and Cp == 128
-        if blocked:
+        mode = _lstm_mode()
+        blocked = dt == torch.bfloat16 and H == 256 and Cp == 128 and mode != "cluster"
+        geom = None if (blocked or mode == "stream") else _cluster_geometry(N, H, d)
+        if geom is not None:
+            # weight-stationary recurrence over a cluster of CUs (lstm_cluster.hip): input projection by GEMM,
+            # W_hh resident in LDS, h exchanged through y; activations saved in the blocked layout
+            xg = _empty((R, 8 * H), dt, dev)
+            gemm_raw(A=xn, B=wih, C=xg, bias=bsum, M=R, N=8 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=1, b_ns=Cp,
+                     c_ms=8 * H, c_ns=1, dtype=d, bias_mode=1)
+            NT = (N + 31) // 32
+            whh = torch.stack([w_hh, w_hh_r]).to(dt).contiguous()              # [2][4H][H]
+            gates = _empty((2, NT, L, 4 * H * 32), dt, dev) if need else None
+            cst = _empty((2, NT, L, H * 32), F32, dev)
+            sync = _empty((lib().dtt_lstm_cluster_sync_words(geom[2]),), torch.int32, dev)
+            check(lib().dtt_lstm_cluster_fwd(ptr(xg), ptr(whh), ptr(y), ptr(gates), ptr(cst), ptr(sync), N, L, heads, H,
+                                             d, stream_ptr()), "dtt_lstm_cluster_fwd")
+        elif blocked:
             # fused input projection, activations saved in the kernels' private blocked layout
             nblk = (N + 31) // 32
+            wp = torch.stack([_pack_whh_fwd(w_hh, dt), _pack_whh_fwd(w_hh_r, dt)]).contiguous()
             wihp = torch.stack([_pack_whh_fwd(w_ih, dt), _pack_whh_fwd(w_ih_r, dt)]).contiguous()
             gates = _empty((2, nblk, L, 4 * H * 32), dt, dev) if need else None
             cst = _empty((2, nblk, L, H * 32), F32, dev) if need else None
@@ -480,6 +508,7 @@ class DualPathRNN(torch.autograd.Function):
                      c_ms=8 * H, c_ns=1, dtype=d, bias_mode=1)
             gates = _empty((R, 2, 4 * H), dt, dev) if need else None
             cst = _empty((R, 2, H), F32, dev)            # always: the cell state round-trips through it
+            wp = torch.stack([_pack_whh_fwd(w_hh, dt), _pack_whh_fwd(w_hh_r, dt)]).contiguous()
             check(lib().dtt_lstm_fwd(ptr(xg), ptr(wp), ptr(y), ptr(gates), ptr(cst), N, L, heads, H, d, stream_ptr()),
                   "dtt_lstm_fwd")
         fcw = fc_w.to(dt).contiguous()                                         # [Cp][4Cp]
@@ -488,14 +517,14 @@ class DualPathRNN(torch.autograd.Function):
         gemm_raw(A=y, B=fcw, C=out, bias=fc_b, R=res, M=R, N=Cp, K=2 * H, a_ms=2 * H, a_ks=1, b_ks=1, b_ns=2 * H,
                  c_ms=Cp, c_ns=1, r_ms=Cp, r_ns=1, dtype=d, bias_mode=1)
         ctx.save_for_backward(x, gamma, xn, gstats, wih, w_hh, w_hh_r, y, gates, cst, fcw)
-        ctx.cfg = (heads, along_f, geo, gs, blocked)
+        ctx.cfg = (heads, along_f, geo, gs, blocked, geom)
         # along_f: memory order is [B,T,F,C]; the view below is the reference's merge_heads quirk
         return out.view(B, Fq, T, Cc)
 
     @staticmethod
     def backward(ctx, dout):
         x, gamma, xn, gstats, wih, w_hh, w_hh_r, y, gates, cst, fcw = ctx.saved_tensors
-        heads, along_f, geo, gs, blocked = ctx.cfg
+        heads, along_f, geo, gs, blocked, geom = ctx.cfg
         nslab, NI, L, Cc, Cp = geo[0], geo[1], geo[2], geo[3], geo[4]
         dt, dev, d = x.dtype, x.device, _dt(x)
         H = w_hh.shape[1]
@@ -513,14 +542,24 @@ class DualPathRNN(torch.autograd.Function):
                  c_ms=2 * H, c_ns=1, dtype=d, atomic=1, out_f32=1)
         dfcb = colsum(dout, R, Cp)
         # recurrent backward
-        wpt = torch.stack([_pack_whh_bwd(w_hh, dt), _pack_whh_bwd(w_hh_r, dt)]).contiguous()
         dG = _empty((R, 2, 4 * H), dt, dev)
         dbias = None
-        if blocked:
+        if geom is not None:
+            N = nslab * heads
+            NT = (N + 31) // 32
+            whhT = torch.stack([w_hh.t(), w_hh_r.t()]).to(dt).contiguous()     # [2][H][4H]
+            dcbuf = _empty((2, NT, H * 32), F32, dev)
+            dbias = _zeros_f32((2 * 4 * H,), dev)
+            sync = _empty((lib().dtt_lstm_cluster_sync_words(geom[2]),), torch.int32, dev)
+            check(lib().dtt_lstm_cluster_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(whhT), ptr(dG), ptr(dcbuf), ptr(dbias),
+                                             ptr(sync), N, L, heads, H, d, stream_ptr()), "dtt_lstm_cluster_bwd")
+        elif blocked:
+            wpt = torch.stack([_pack_whh_bwd(w_hh, dt), _pack_whh_bwd(w_hh_r, dt)]).contiguous()
             dbias = _zeros_f32((2 * 4 * H,), dev)           # bias gradient accumulated inside the kernel
             check(lib().dtt_lstm_bwd_blk(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), ptr(dbias), nslab * heads,
                                          L, heads, H, d, stream_ptr()), "dtt_lstm_bwd_blk")
         else:
+            wpt = torch.stack([_pack_whh_bwd(w_hh, dt), _pack_whh_bwd(w_hh_r, dt)]).contiguous()
             check(lib().dtt_lstm_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), nslab * heads, L, heads, H, d,
                                      stream_ptr()), "dtt_lstm_bwd")
         G4 = 4 * H

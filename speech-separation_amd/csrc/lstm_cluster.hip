@@ -98,28 +98,57 @@ __device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, uns
     }
     __syncthreads();
 }
+// EVERY storing wave drains its sc1 stores, then the workgroup barrier, then ONE lane signals for all of them.
+// The exchanged slice is stored FIRST and the wave's private stores (saved activations, running state) behind
+// it: vmcnt retires in issue order, so waiting until only those AFTER younger operations are outstanding drains
+// exactly the exchanged bytes and keeps the private stores' write-back off the critical path of the step.
+template <int AFTER>
 __device__ __forceinline__ void signal_counter(unsigned* cnt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its sc1 stores ...
-    __syncthreads();                                        // ... before the ONE lane signals for all of them
+    static_assert(AFTER == 0 || AFTER == 4 || AFTER == 12 || AFTER == 20, "counted drain");
+    if (AFTER == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (AFTER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (AFTER == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (AFTER == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Role of a workgroup.  Workgroups b and b + 8 land on the same XCD (observed dispatch order; speed only, nothing
+// depends on it): when the (direction, sequence group) pairs divide evenly over the 8 XCDs, the G workgroups of a
+// group are given ids of one residue class, so that the slice one of them publishes is fetched into that XCD's L2
+// once and the other G - 1 readers hit it there.
+__device__ __forceinline__ void cluster_role(int b, int G, int S, int& dir, int& sg, int& cg) {
+    const int P = 2 * S;
+    int q;
+    if (P % 8 == 0) {
+        const int x = b & 7, i = b >> 3;
+        q = x * (P >> 3) + i / G;
+        cg = i % G;
+    } else {
+        q = b / G;
+        cg = b % G;
+    }
+    dir = q / S;
+    sg = q - dir * S;
 }
 
 // UT = U / 32 unit tiles per workgroup (1 or 2); WLDS: the W_hh slice lives in LDS (else it is streamed from L2
 // every step: the fp32 parity mode and widths whose slice does not fit).
-template <typename T, int UT, bool WLDS>
+template <typename T, int AB, bool WLDS>
 __global__ __launch_bounds__(512) void lstm_cluster_fwd_kernel(LstmCP p) {
+    constexpr int UT = 1;                                   // unit tiles per workgroup (U = 32)
     constexpr int ES = sizeof(T), EPC = 16 / ES;            // elements per 16-byte chunk
     constexpr int CPR = 32 / EPC;                           // chunks per 32-unit row segment (4 / 8)
     constexpr int CPL = 32 * CPR / 64;                      // chunks of a 32 x 32 tile per lane (2 / 4)
     constexpr int LDS_ROW = 32 + EPC;                       // staging row stride (elements)
-    constexpr int AB = (ES == 2 ? 32 : 8) / UT;             // A fragments (k-steps) in flight per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = p.H, U = UT * 32, LDW = H + MM<T>::PAD, KS = H / 16, G4 = 4 * H;
     T* wbuf = reinterpret_cast<T*>(smem);                                   // [4U][LDW]           (WLDS)
     T* stg_all = wbuf + (WLDS ? (size_t)4 * U * LDW : 0);                   // [8 waves][32][LDS_ROW]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     T* stg = stg_all + wave * 32 * LDS_ROW;
-    const int cg = blockIdx.x % p.G, sg = (blockIdx.x / p.G) % p.S, dir = blockIdx.x / (p.G * p.S);
+    int cg, sg, dir;
+    cluster_role(blockIdx.x, p.G, p.S, dir, sg, cg);
     const int u0 = cg * U;
     const int tile0 = sg * p.TPG, ntile = min(p.TPG, p.NT - tile0);
     unsigned* cnt = p.sync + (size_t)(dir * p.S + sg) * SYNC_STRIDE;
@@ -139,6 +168,13 @@ __global__ __launch_bounds__(512) void lstm_cluster_fwd_kernel(LstmCP p) {
     __syncthreads();
     if (ntile <= 0) return;                                // (the host never launches empty groups)
     bool dead = false;
+    // every wave owns at most one row tile: its cell state stays in registers (cst is still written for backward)
+    const bool inreg = ntile <= 8;
+    float creg[UT][16];
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) creg[ut][r] = 0.f;
 
     for (int s = 0; s < p.L; ++s) {
         const int t = dir ? p.L - 1 - s : s;
@@ -203,90 +239,104 @@ __global__ __launch_bounds__(512) void lstm_cluster_fwd_kernel(LstmCP p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[ut][g][r] = ldf(stg + ((r & 3) + 8 * (r >> 2) + 4 * lh) * LDS_ROW + lr);
                 }
+            // ---- previous cell state: it lives in creg across steps when the wave owns one tile; with several tiles per
+            // wave it comes back from the cst buffer this same lane wrote one step ago (issued ahead of the A fragments
+            // so that the two latencies overlap)
+            const size_t slab = ((size_t)dir * p.NT + gt) * p.L + t;
+            if (!inreg) {
+#pragma unroll
+                for (int ut = 0; ut < UT; ++ut) {
+                    const size_t slabp = ((size_t)dir * p.NT + gt) * p.L + (s > 0 ? tprev : t);
+                    const float* cs = p.cst + (slabp * H + u0 + ut * 32 + lr) * 32 + lh * 16;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(cs + q * 4);
+                        creg[ut][q * 4] = s > 0 ? v.x : 0.f; creg[ut][q * 4 + 1] = s > 0 ? v.y : 0.f;
+                        creg[ut][q * 4 + 2] = s > 0 ? v.z : 0.f; creg[ut][q * 4 + 3] = s > 0 ? v.w : 0.f;
+                    }
+                }
+            }
             // ---- recurrent term: A fragments of h_{t-1} straight from the exchange buffer (sc1).  The loop is bound by
             // the latency of these loads, not by their bandwidth: a whole batch of AB k-steps is put in flight at once
             if (s > 0) {
                 const unsigned baseA = okA ? (((rbA + (unsigned)(tprev * p.heads)) * 2u + dir) * (unsigned)H + lh * 8) * ES : OOB;
-                for (int kb = 0; kb < KS; kb += AB) {
-                    const int nk = min(AB, KS - kb);
-                    AFrag<T> aq[AB];
+                // a rolling window of AB fragments: a slot is re-issued as soon as its fragment has been consumed.  NO
+                // branch inside the main loop (hipcc merges wait counts across branches into vmcnt(0) per MFMA, which
+                // serialises the window): the refill past the end selects an out-of-range offset instead
+                AFrag<T> aq[AB];
+                const int KM = KS;                         // the host picks AB as a divisor of KS
 #pragma unroll
-                    for (int d = 0; d < AB; ++d) aq[d].load(ry, (baseA == OOB || d >= nk) ? OOB : baseA + (kb + d) * 16 * ES);
+                for (int d = 0; d < AB; ++d) aq[d].load(ry, (baseA == OOB || d >= KS) ? OOB : baseA + d * 16 * ES);
+                for (int kb = 0; kb < KM; kb += AB) {
 #pragma unroll
                     for (int d = 0; d < AB; ++d) {
-                        if (d < nk) {
-                            const int k = kb + d;
-                            const typename MM<T>::Frag af = aq[d].frag();
+                        const int k = kb + d;
+                        const typename MM<T>::Frag af = aq[d].frag();
+                        aq[d].load(ry, (baseA == OOB || k + AB >= KS) ? OOB : baseA + (k + AB) * 16 * ES);
 #pragma unroll
-                            for (int ut = 0; ut < UT; ++ut)
+                        for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
-                                for (int g = 0; g < 4; ++g) {
-                                    typename MM<T>::Frag bq;
-                                    if (WLDS) bq = MM<T>::ldfrag(wbuf + (size_t)(g * U + ut * 32 + lr) * LDW + k * 16 + lh * 8);
-                                    else bq = MM<T>::ldfrag(whh + ((size_t)g * H + u0 + ut * 32 + lr) * H + k * 16 + lh * 8);
-                                    MM<T>::mma(af, bq, acc[ut][g]);
-                                }
-                        }
-                    }
-                }
-            }
-            // ---- gates, state update; h_t -> staging -> 16-byte sc1 stores FIRST (they are what the other CUs wait for)
-            const size_t slab = ((size_t)dir * p.NT + gt) * p.L + t;
-            const size_t slabp = ((size_t)dir * p.NT + gt) * p.L + tprev;
-#pragma unroll
-            for (int ut = 0; ut < UT; ++ut) {
-                const int j = u0 + ut * 32 + lr;
-                float cp[16];
-                if (s > 0) {
-                    const float* cs = p.cst + (slabp * H + j) * 32 + lh * 16;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = *reinterpret_cast<const float4*>(cs + q * 4);
-                        cp[q * 4] = v.x; cp[q * 4 + 1] = v.y; cp[q * 4 + 2] = v.z; cp[q * 4 + 3] = v.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) cp[r] = 0.f;
-                }
-                // gate math in two halves of 8 rows (register pressure): h_t into the staging tile, activations and
-                // cell state straight out as 16-byte vectors in the blocked layout
-                float* cd = p.cst + (slab * H + j) * 32 + lh * 16;
-                T* gd = reinterpret_cast<T*>(p.gates) + ((slab * 4) * H + j) * 32 + lh * 16;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    float gv[4][8], cn[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int r = hf * 8 + e;
-                        gv[0][e] = sigm_t<T>(acc[ut][0][r]); gv[1][e] = sigm_t<T>(acc[ut][1][r]);
-                        gv[2][e] = tanh_t<T>(acc[ut][2][r]); gv[3][e] = sigm_t<T>(acc[ut][3][r]);
-                        cn[e] = gv[1][e] * cp[r] + gv[0][e] * gv[2][e];
-                        stf(stg + ((r & 3) + 8 * (r >> 2) + 4 * lh) * LDS_ROW + lr, gv[3][e] * tanh_t<T>(cn[e]));
-                    }
-                    *reinterpret_cast<float4*>(cd + hf * 8) = make_float4(cn[0], cn[1], cn[2], cn[3]);
-                    *reinterpret_cast<float4*>(cd + hf * 8 + 4) = make_float4(cn[4], cn[5], cn[6], cn[7]);
-                    if (p.gates) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int q = 0; q < 8 / EPC; ++q) {
-                                Vec16<T> v;
-#pragma unroll
-                                for (int e = 0; e < EPC; ++e) v.set(e, gv[g][q * EPC + e]);
-                                st16<T>(gd + (size_t)g * H * 32 + hf * 8 + q * EPC, v);
+                            for (int g = 0; g < 4; ++g) {
+                                typename MM<T>::Frag bq;
+                                if (WLDS) bq = MM<T>::ldfrag(wbuf + (size_t)(g * U + ut * 32 + lr) * LDW + k * 16 + lh * 8);
+                                else bq = MM<T>::ldfrag(whh + ((size_t)g * H + u0 + ut * 32 + lr) * H + k * 16 + lh * 8);
+                                MM<T>::mma(af, bq, acc[ut][g]);
                             }
                     }
                 }
-                // h_t slice: 16-byte write-through stores (what the other CUs of the group wait for)
+            }
+            // ---- gates, state update.  h_t goes out FIRST (staging -> 16-byte write-through stores: what the other CUs
+            // of the group wait for), the saved activations behind it.
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) {
+                const int j = u0 + ut * 32 + lr;
+                Vec16<T> gpk[4][16 / EPC];                 // gates packed as they are computed (register pressure)
+#pragma unroll
+                for (int q = 0; q < 16 / EPC; ++q) {
+                    float gv[4][EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const int r = q * EPC + e;
+                        gv[0][e] = sigm_t<T>(acc[ut][0][r]); gv[1][e] = sigm_t<T>(acc[ut][1][r]);
+                        gv[2][e] = tanh_t<T>(acc[ut][2][r]); gv[3][e] = sigm_t<T>(acc[ut][3][r]);
+                        const float c = gv[1][e] * creg[ut][r] + gv[0][e] * gv[2][e];
+                        creg[ut][r] = c;
+                        stf(stg + ((r & 3) + 8 * (r >> 2) + 4 * lh) * LDS_ROW + lr, gv[3][e] * tanh_t<T>(c));
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if constexpr (ES == 2) {
+#pragma unroll
+                            for (int e = 0; e < EPC; e += 2) gpk[g][q].set2(e, gv[g][e], gv[g][e + 1]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) gpk[g][q].set(e, gv[g][e]);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const int ci = lane + 64 * c, row = ci / CPR, part = ci - row * CPR;
                     const u32x4_t v = *reinterpret_cast<const u32x4_t*>(stg + row * LDS_ROW + part * EPC);
                     st_sc1(ry, offC[c] == OOB ? OOB : offC[c] + (unsigned)(ut * 32) * ES, v);
                 }
+                asm volatile("" ::: "memory");             // the private stores stay behind the exchanged ones
+                float* cd = p.cst + (slab * H + j) * 32 + lh * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(cd + q * 4) = make_float4(creg[ut][q * 4], creg[ut][q * 4 + 1], creg[ut][q * 4 + 2], creg[ut][q * 4 + 3]);
+                if (p.gates) {
+                    T* gd = reinterpret_cast<T*>(p.gates) + ((slab * 4) * H + j) * 32 + lh * 16;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int q = 0; q < 16 / EPC; ++q) st16<T>(gd + (size_t)g * H * 32 + q * EPC, gpk[g][q]);
+                }
             }
         }
-        if (s + 1 < p.L) signal_counter(cnt);
+        if (s + 1 < p.L) {
+            if (p.gates) signal_counter<4 + 4 * (16 / EPC)>(cnt); else signal_counter<4>(cnt);
+        }
     }
 }
 
@@ -309,16 +359,18 @@ struct LstmCBP {
     int N, L, heads, H, U, G, S, NT, TPG;
 };
 
-template <typename T, int UT, bool WLDS>
+template <typename T, int AB, bool WLDS>
 __global__ __launch_bounds__(512) void lstm_cluster_bwd_kernel(LstmCBP p) {
-    constexpr int ES = sizeof(T), EPC = 16 / ES, CPR = 32 / EPC, CPL = 32 * CPR / 64, LDS_ROW = 32 + EPC, AB = ES == 2 ? 32 : 8;
+    constexpr int UT = 1;
+    constexpr int ES = sizeof(T), EPC = 16 / ES, CPR = 32 / EPC, CPL = 32 * CPR / 64, LDS_ROW = 32 + EPC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = p.H, U = UT * 32, G4 = 4 * H, LDW = G4 + MM<T>::PAD, KS = G4 / 16;
     T* wbuf = reinterpret_cast<T*>(smem);                                   // [U][LDW]   (WLDS)
     T* stg_all = wbuf + (WLDS ? (size_t)U * LDW : 0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     T* stg = stg_all + wave * 32 * LDS_ROW;
-    const int cg = blockIdx.x % p.G, sg = (blockIdx.x / p.G) % p.S, dir = blockIdx.x / (p.G * p.S);
+    int cg, sg, dir;
+    cluster_role(blockIdx.x, p.G, p.S, dir, sg, cg);
     const int u0 = cg * U;
     const int tile0 = sg * p.TPG, ntile = min(p.TPG, p.NT - tile0);
     unsigned* cnt = p.sync + (size_t)(dir * p.S + sg) * SYNC_STRIDE;
@@ -344,26 +396,94 @@ __global__ __launch_bounds__(512) void lstm_cluster_bwd_kernel(LstmCBP p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) dbs[ut][g] = 0.f;
 
+    // every wave owns at most one row tile: c_t and the running dc stay in registers across steps
+    const bool inreg = ntile <= 8;
+    float cc[UT][16], dc[UT][16];
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { cc[ut][r] = 0.f; dc[ut][r] = 0.f; }
+
     for (int s = p.L - 1; s >= 0; --s) {
         const int t = dir ? p.L - 1 - s : s;
         const int tprev = dir ? t + 1 : t - 1;            // forward-pass predecessor (its c is c_{t-1})
         const int tnext = dir ? t - 1 : t + 1;            // step processed in the previous iteration
         const bool first = s == p.L - 1;
+        // what the gate math of a tile needs besides dh does not depend on the exchange: for the wave's first tile it
+        // is requested ahead of the wait (saved gates, c_{t-1}, the dy tile)
+        Vec16<T> gq[UT][4][16 / EPC];
+        float4 cpq[UT][4];
+        u32x4_t dyq[UT][CPL];
+        auto prefetch = [&](int tl) {
+            const int gt = tile0 + tl;
+            const size_t slab = ((size_t)dir * p.NT + gt) * p.L + t;
+            const size_t slabp = ((size_t)dir * p.NT + gt) * p.L + (s > 0 ? tprev : t);
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) {
+                const int j = u0 + ut * 32 + lr;
+                const T* gs = reinterpret_cast<const T*>(p.gates) + ((slab * 4) * H + j) * 32 + lh * 16;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int q = 0; q < 16 / EPC; ++q) gq[ut][g][q] = ld16<T>(gs + (size_t)g * H * 32 + q * EPC);
+                const float* cps = p.cst + (slabp * H + j) * 32 + lh * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cpq[ut][q] = *reinterpret_cast<const float4*>(cps + q * 4);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int ci = lane + 64 * c, row = ci / CPR, part = ci - row * CPR, n = gt * 32 + row;
+                    const bool ok = n < p.N;
+                    const unsigned rb = ok ? (unsigned)((n / p.heads) * p.L * p.heads + (n % p.heads) + t * p.heads) : 0u;
+                    dyq[ut][c] = __builtin_amdgcn_raw_buffer_load_b128(rdy, ok ? ((rb * 2u + dir) * (unsigned)H + u0 + ut * 32 + part * EPC) * ES : OOB, 0, 0);
+                }
+            }
+        };
+        auto load_state = [&](int tl) {                    // c_t (and the running dc) of a tile from memory
+            const int gt = tile0 + tl;
+            const size_t slab = ((size_t)dir * p.NT + gt) * p.L + t;
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) {
+                const int j = u0 + ut * 32 + lr;
+                const float* cs = p.cst + (slab * H + j) * 32 + lh * 16;
+                const float* dcs = p.dcbuf + ((((size_t)dir * p.NT + gt) * H + j) * 32 + lh * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = *reinterpret_cast<const float4*>(cs + q * 4);
+                    cc[ut][q * 4] = a.x; cc[ut][q * 4 + 1] = a.y; cc[ut][q * 4 + 2] = a.z; cc[ut][q * 4 + 3] = a.w;
+                    if (!first && !inreg) {
+                        const float4 d = *reinterpret_cast<const float4*>(dcs + q * 4);
+                        dc[ut][q * 4] = d.x; dc[ut][q * 4 + 1] = d.y; dc[ut][q * 4 + 2] = d.z; dc[ut][q * 4 + 3] = d.w;
+                    }
+                }
+            }
+        };
+        if (wave < ntile) {
+            prefetch(wave);
+            if (first && inreg) load_state(wave);
+        }
         if (!first) wait_counter(cnt, (unsigned)(p.G * (p.L - 1 - s)), status, dead);
         for (int tl = wave; tl < ntile; tl += 8) {
             const int gt = tile0 + tl, n0 = gt * 32;
             const int nA = n0 + lr;
             const bool okA = nA < p.N;
             const unsigned rbA = okA ? (unsigned)((nA / p.heads) * p.L * p.heads + (nA % p.heads)) : 0u;
-            unsigned offY[CPL], offG[CPL];                 // this lane's chunks of the dy tile / dG tile at step t
-            bool okC[CPL];
+            unsigned offG[CPL];                            // this lane's chunks of the dG tile at step t
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int ci = lane + 64 * c, row = ci / CPR, part = ci - row * CPR, n = n0 + row;
-                okC[c] = n < p.N;
-                const unsigned rb = okC[c] ? (unsigned)((n / p.heads) * p.L * p.heads + (n % p.heads) + t * p.heads) : 0u;
-                offY[c] = okC[c] ? ((rb * 2u + dir) * (unsigned)H + u0 + part * EPC) * ES : OOB;
-                offG[c] = okC[c] ? ((rb * 2u + dir) * (unsigned)G4 + u0 + part * EPC) * ES : OOB;
+                const bool ok = n < p.N;
+                const unsigned rb = ok ? (unsigned)((n / p.heads) * p.L * p.heads + (n % p.heads) + t * p.heads) : 0u;
+                offG[c] = ok ? ((rb * 2u + dir) * (unsigned)G4 + u0 + part * EPC) * ES : OOB;
+            }
+            if (tl != wave) prefetch(tl);
+            if (!inreg) {
+                if (first) {
+#pragma unroll
+                    for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dc[ut][r] = 0.f;
+                }
+                load_state(tl);
             }
             // ---- dh_t <- dG_{t+1} . W_hh[:, units]: A fragments straight from the exchange buffer
             f32x16_t dh[UT];
@@ -373,91 +493,56 @@ __global__ __launch_bounds__(512) void lstm_cluster_bwd_kernel(LstmCBP p) {
                 for (int r = 0; r < 16; ++r) dh[ut][r] = 0.f;
             if (!first) {
                 const unsigned baseA = okA ? (((rbA + (unsigned)(tnext * p.heads)) * 2u + dir) * (unsigned)G4 + lh * 8) * ES : OOB;
-                for (int kb = 0; kb < KS; kb += AB) {      // latency-bound: a whole batch of k-steps in flight at once
-                    const int nk = min(AB, KS - kb);
-                    AFrag<T> aq[AB];
+                // latency-bound: a rolling window of AB fragments in flight, a slot re-issued once consumed; no branch in
+                // the main loop (see the forward kernel)
+                AFrag<T> aq[AB];
+                const int KM = KS;                         // the host picks AB as a divisor of KS
 #pragma unroll
-                    for (int d = 0; d < AB; ++d) aq[d].load(rg, (baseA == OOB || d >= nk) ? OOB : baseA + (kb + d) * 16 * ES);
+                for (int d = 0; d < AB; ++d) aq[d].load(rg, (baseA == OOB || d >= KS) ? OOB : baseA + d * 16 * ES);
+                for (int kb = 0; kb < KM; kb += AB) {
 #pragma unroll
                     for (int d = 0; d < AB; ++d) {
-                        if (d < nk) {
-                            const int k = kb + d;
-                            const typename MM<T>::Frag af = aq[d].frag();
+                        const int k = kb + d;
+                        const typename MM<T>::Frag af = aq[d].frag();
+                        aq[d].load(rg, (baseA == OOB || k + AB >= KS) ? OOB : baseA + (k + AB) * 16 * ES);
 #pragma unroll
-                            for (int ut = 0; ut < UT; ++ut) {
-                                typename MM<T>::Frag bq;
-                                if (WLDS) bq = MM<T>::ldfrag(wbuf + (size_t)(ut * 32 + lr) * LDW + k * 16 + lh * 8);
-                                else bq = MM<T>::ldfrag(whhT + (size_t)(u0 + ut * 32 + lr) * G4 + k * 16 + lh * 8);
-                                MM<T>::mma(af, bq, dh[ut]);
-                            }
+                        for (int ut = 0; ut < UT; ++ut) {
+                            typename MM<T>::Frag bq;
+                            if (WLDS) bq = MM<T>::ldfrag(wbuf + (size_t)(ut * 32 + lr) * LDW + k * 16 + lh * 8);
+                            else bq = MM<T>::ldfrag(whhT + (size_t)(u0 + ut * 32 + lr) * G4 + k * 16 + lh * 8);
+                            MM<T>::mma(af, bq, dh[ut]);
                         }
                     }
                 }
             }
-            const size_t slab = ((size_t)dir * p.NT + gt) * p.L + t;
-            const size_t slabp = ((size_t)dir * p.NT + gt) * p.L + tprev;
 #pragma unroll
             for (int ut = 0; ut < UT; ++ut) {
                 const int j = u0 + ut * 32 + lr;
                 // dy tile through the staging buffer
-                {
-                    u32x4_t q[CPL];
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c)
-                        q[c] = __builtin_amdgcn_raw_buffer_load_b128(rdy, offY[c] == OOB ? OOB : offY[c] + (unsigned)(ut * 32) * ES, 0, 0);
-#pragma unroll
-                    for (int c = 0; c < CPL; ++c) {
-                        const int ci = lane + 64 * c, row = ci / CPR, part = ci - row * CPR;
-                        *reinterpret_cast<u32x4_t*>(stg + row * LDS_ROW + part * EPC) = q[c];
-                    }
-                }
-                // saved activations (blocked: 16 values per lane and gate), cell states, running dc
-                float gi[16], gf[16], gg[16], go[16], cc[16], cp[16], dc[16];
-                {
-                    const T* gs = reinterpret_cast<const T*>(p.gates) + ((slab * 4) * H + j) * 32 + lh * 16;
-                    float* gdst[4] = {gi, gf, gg, go};
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int q = 0; q < 16 / EPC; ++q) {
-                            const Vec16<T> v = ld16<T>(gs + (size_t)g * H * 32 + q * EPC);
-#pragma unroll
-                            for (int e = 0; e < EPC; ++e) gdst[g][q * EPC + e] = v.get(e);
-                        }
-                    const float* cs = p.cst + (slab * H + j) * 32 + lh * 16;
-                    const float* cps = p.cst + (slabp * H + j) * 32 + lh * 16;
-                    const float* dcs = p.dcbuf + ((((size_t)dir * p.NT + gt) * H + j) * 32 + lh * 16);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 a = *reinterpret_cast<const float4*>(cs + q * 4);
-                        cc[q * 4] = a.x; cc[q * 4 + 1] = a.y; cc[q * 4 + 2] = a.z; cc[q * 4 + 3] = a.w;
-                        float4 b = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (s > 0) b = *reinterpret_cast<const float4*>(cps + q * 4);
-                        if (!first) d = *reinterpret_cast<const float4*>(dcs + q * 4);
-                        cp[q * 4] = b.x; cp[q * 4 + 1] = b.y; cp[q * 4 + 2] = b.z; cp[q * 4 + 3] = b.w;
-                        dc[q * 4] = d.x; dc[q * 4 + 1] = d.y; dc[q * 4 + 2] = d.z; dc[q * 4 + 3] = d.w;
-                    }
+                for (int c = 0; c < CPL; ++c) {
+                    const int ci = lane + 64 * c, row = ci / CPR, part = ci - row * CPR;
+                    *reinterpret_cast<u32x4_t*>(stg + row * LDS_ROW + part * EPC) = dyq[ut][c];
                 }
                 float di[16], df[16], dg[16], dox[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
                     const bool ok = n0 + nl < p.N;
+                    const float gi = gq[ut][0][r / EPC].get(r % EPC), gf = gq[ut][1][r / EPC].get(r % EPC);
+                    const float gg = gq[ut][2][r / EPC].get(r % EPC), go = gq[ut][3][r / EPC].get(r % EPC);
+                    const float cpv = s > 0 ? (&cpq[ut][r >> 2].x)[r & 3] : 0.f;
                     const float dhv = ldf(stg + nl * LDS_ROW + lr) + dh[ut][r];
-                    const float tc = tanh_t<T>(cc[r]);
-                    const float dcv = dc[r] + dhv * go[r] * (1.f - tc * tc);
-                    dox[r] = ok ? dhv * tc * go[r] * (1.f - go[r]) : 0.f;
-                    di[r] = ok ? dcv * gg[r] * gi[r] * (1.f - gi[r]) : 0.f;
-                    df[r] = ok ? dcv * cp[r] * gf[r] * (1.f - gf[r]) : 0.f;
-                    dg[r] = ok ? dcv * gi[r] * (1.f - gg[r] * gg[r]) : 0.f;
-                    dc[r] = dcv * gf[r];
+                    const float tc = tanh_t<T>(cc[ut][r]);
+                    const float dcv = dc[ut][r] + dhv * go * (1.f - tc * tc);
+                    dox[r] = ok ? dhv * tc * go * (1.f - go) : 0.f;
+                    di[r] = ok ? dcv * gg * gi * (1.f - gi) : 0.f;
+                    df[r] = ok ? dcv * cpv * gf * (1.f - gf) : 0.f;
+                    dg[r] = ok ? dcv * gi * (1.f - gg * gg) : 0.f;
+                    dc[ut][r] = dcv * gf;
+                    cc[ut][r] = cpv;                       // c_{t-1} is the next iteration's c_t
                 }
-                if (s > 0) {
-                    float* dcd = p.dcbuf + ((((size_t)dir * p.NT + gt) * H + j) * 32 + lh * 16);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dcd + q * 4) = make_float4(dc[q * 4], dc[q * 4 + 1], dc[q * 4 + 2], dc[q * 4 + 3]);
-                }
-                // gate gradients -> staging -> row-major 16-byte sc1 stores, one gate at a time
+                // gate gradients FIRST (the other CUs wait for them): staging -> row-major 16-byte sc1 stores
                 const float* gsrc[4] = {di, df, dg, dox};
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -475,9 +560,18 @@ __global__ __launch_bounds__(512) void lstm_cluster_bwd_kernel(LstmCBP p) {
                         st_sc1(rg, offG[c] == OOB ? OOB : offG[c] + (unsigned)(g * H + ut * 32) * ES, v);
                     }
                 }
+                asm volatile("" ::: "memory");             // the private store stays behind the exchanged ones
+                if (!inreg && s > 0) {
+                    float* dcd = p.dcbuf + ((((size_t)dir * p.NT + gt) * H + j) * 32 + lh * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(dcd + q * 4) = make_float4(dc[ut][q * 4], dc[ut][q * 4 + 1], dc[ut][q * 4 + 2], dc[ut][q * 4 + 3]);
+                }
             }
         }
-        if (s > 0) signal_counter(cnt);
+        if (s > 0) {
+            if (inreg) signal_counter<0>(cnt); else signal_counter<4>(cnt);
+        }
     }
     if (p.dbias) {
 #pragma unroll
@@ -520,7 +614,7 @@ extern "C" int dtt_lstm_cluster_geometry(int N, int H, int dtype, int* U, int* G
     const int ncu = num_cus();
     if (H < 32 || H % 32 != 0 || N <= 0 || ncu <= 0) return 1;
     int u = 32;
-    if (dtype == 1 && H % 64 == 0 && cluster_fwd_lds(H, 64, 2, true) <= LDS_CAP && cluster_bwd_lds(H, 64, 2, true) <= LDS_CAP) u = 64;
+    (void)dtype;                                            // (a 64-unit variant exists in the templates; it spills and is not used)
     const int g = H / u;
     if (2 * g > ncu) return 1;
     const int nt = (N + 31) / 32;
@@ -552,11 +646,12 @@ extern "C" int dtt_lstm_cluster_fwd(const void* xg, const void* whh, void* y, vo
 #define LAUNCH_CF(TT, UTV, WL) do { auto k = lstm_cluster_fwd_kernel<TT, UTV, WL>; \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
+    const int KS = H / 16;                                  // k-steps: the window depth AB must divide it
     if (dtype) {
-        if (U == 64) { if (wlds) LAUNCH_CF(bf16, 2, true); else LAUNCH_CF(bf16, 2, false); }
-        else { if (wlds) LAUNCH_CF(bf16, 1, true); else LAUNCH_CF(bf16, 1, false); }
+        if (wlds) { if (KS % 16 == 0) LAUNCH_CF(bf16, 16, true); else if (KS % 8 == 0) LAUNCH_CF(bf16, 8, true); else if (KS % 4 == 0) LAUNCH_CF(bf16, 4, true); else LAUNCH_CF(bf16, 2, true); }
+        else { if (KS % 16 == 0) LAUNCH_CF(bf16, 16, false); else if (KS % 4 == 0) LAUNCH_CF(bf16, 4, false); else LAUNCH_CF(bf16, 2, false); }
     } else {
-        LAUNCH_CF(float, 1, false);
+        if (KS % 4 == 0) LAUNCH_CF(float, 4, false); else LAUNCH_CF(float, 2, false);
     }
 #undef LAUNCH_CF
     DTT_LAUNCH_CHECK();
@@ -585,11 +680,12 @@ extern "C" int dtt_lstm_cluster_bwd(const void* dy, const void* gates_blk, const
 #define LAUNCH_CB(TT, UTV, WL) do { auto k = lstm_cluster_bwd_kernel<TT, UTV, WL>; \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
+    const int KS = 4 * H / 16;
     if (dtype) {
-        if (U == 64) { if (wlds) LAUNCH_CB(bf16, 2, true); else LAUNCH_CB(bf16, 2, false); }
-        else { if (wlds) LAUNCH_CB(bf16, 1, true); else LAUNCH_CB(bf16, 1, false); }
+        if (wlds) { if (KS % 16 == 0) LAUNCH_CB(bf16, 16, true); else LAUNCH_CB(bf16, 8, true); }
+        else { if (KS % 16 == 0) LAUNCH_CB(bf16, 16, false); else LAUNCH_CB(bf16, 8, false); }
     } else {
-        LAUNCH_CB(float, 1, false);
+        LAUNCH_CB(float, 4, false);
     }
 #undef LAUNCH_CB
     DTT_LAUNCH_CHECK();

@@ -234,6 +234,24 @@ int dtt_bcat_fwd(const void* x, const float* enh, void* out, int B, int F, int T
 int dtt_bcat_bwd(const void* dout, const float* dtok, void* dx, float* denh, int B, int F, int T, int C, int dtype,
                  void* stream);
 
+/* BatchNorm (+ residual) + activation on channels-last [P pixels][C] tensors, for the lip encoders on the
+ * audio-visual path (VideoEncoders/resnet.py:36-81: bn -> swish; bn -> + residual -> swish; downsample bn;
+ * resnet_video_encoder.py:40-44).  z = act(gamma * (x - mean) * rstd + beta (+ res)); act: 0 none, 1 swish, 2 relu.
+ * stats [C][2] = {mean, rstd}: batch statistics from dtt_in_stats(B = 1) in training, dtt_bn_frozen_stats(running
+ * buffers) in eval.  Backward recomputes the activation input from x (and res): dx, dres (= gradient at the
+ * activation input; may be NULL), dgb [C][2] = {dgamma, dbeta}; partial: dtt_bn_chunks(P) * C * 2 floats, sums
+ * [C][2] floats of scratch.  dtt_bn_running: nn.BatchNorm's running-statistics update (unbiased variance). */
+int dtt_bn_chunks(int P);
+int dtt_bn_act_fwd(const void* x, const void* res, const float* stats, const float* gamma, const float* beta, void* z,
+                   int P, int C, int act, int dtype, void* stream);
+int dtt_bn_act_bwd(const void* x, const void* res, const void* dz, const float* stats, const float* gamma,
+                   const float* beta, float* partial, float* sums, float* dgb, void* dx, void* dres, int P, int C,
+                   int act, int training, int dtype, void* stream);
+int dtt_bn_running(const float* stats, float* running_mean, float* running_var, int C, int64_t n, float momentum,
+                   float eps, void* stream);
+int dtt_bn_frozen_stats(const float* running_mean, const float* running_var, float* stats, int C, float eps,
+                        void* stream);
+
 /* Gradient clip + AdamW over a table of fp32 tensors in two launches (the step after the hot path:
  * torch.optim.AdamW of train.yaml:20-23 after clip_grad_norm_ of base_trainer.py:478-490, train.yaml:59).
  * tab / chunks are device arrays; chunks[c] = {tensor index, chunk index} with chunks of

@@ -977,3 +977,71 @@ class BroadcastConcat(torch.autograd.Function):
         check(lib().dtt_bcat_bwd(ptr(dout), None, ptr(dx), ptr(denh), B, Fq, T, Cc, _dt(dout), stream_ptr()),
               "dtt_bcat_bwd")
         return dx, denh
+
+
+# --------------------------------------------------------------------------- #
+# BatchNorm (+ residual) + activation of the lip encoders (channels-last)
+# --------------------------------------------------------------------------- #
+class BatchNormAct(torch.autograd.Function):
+    """act(batch_norm(x) (+ res)) on an NCHW tensor held in channels-last memory (what the convolutions of the
+    lip encoder produce under bf16 autocast).  VideoEncoders/resnet.py:36-81: bn1 -> swish, bn2 -> + residual ->
+    swish, downsample bn (act 0).  Batch statistics + running-buffer update in training mode, running statistics in
+    eval mode; nothing but x (and res) is saved: backward recomputes the activation input."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, rmean, rvar, training, momentum, eps, act):
+        if x.dim() != 4:
+            raise DttError("BatchNormAct expects an NCHW tensor")
+        x = x.contiguous(memory_format=torch.channels_last)
+        if res is not None:
+            res = res.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        Nb, Cc, Hh, Ww = x.shape
+        P = Nb * Hh * Ww
+        d, dev = _dt(x), x.device
+        stats = _empty((Cc, 2), F32, dev)
+        if training:
+            chunk = _in_chunk(1, P)
+            part = _empty((1, (P + chunk - 1) // chunk, Cc, 2), F32, dev)
+            check(lib().dtt_in_stats(ptr(x), ptr(part), ptr(stats), 1, P, Cc, chunk, C.c_float(eps), d, stream_ptr()),
+                  "dtt_in_stats")
+            if rmean is not None:
+                check(lib().dtt_bn_running(ptr(stats), ptr(rmean), ptr(rvar), Cc, C.c_int64(P), C.c_float(momentum),
+                                           C.c_float(eps), stream_ptr()), "dtt_bn_running")
+        else:
+            check(lib().dtt_bn_frozen_stats(ptr(rmean), ptr(rvar), ptr(stats), Cc, C.c_float(eps), stream_ptr()),
+                  "dtt_bn_frozen_stats")
+        z = torch.empty_like(x)                                 # channels-last, as x
+        check(lib().dtt_bn_act_fwd(ptr(x), ptr(res), ptr(stats), ptr(gamma), ptr(beta), ptr(z), P, Cc, act, d,
+                                   stream_ptr()), "dtt_bn_act_fwd")
+        ctx.save_for_backward(x, res, stats, gamma, beta)
+        ctx.cfg = (act, bool(training))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, res, stats, gamma, beta = ctx.saved_tensors
+        act, training = ctx.cfg
+        Nb, Cc, Hh, Ww = x.shape
+        P = Nb * Hh * Ww
+        d, dev = _dt(x), x.device
+        dz = dz.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        nch = lib().dtt_bn_chunks(P)
+        part = _empty((nch, Cc, 2), F32, dev)
+        sums = _empty((Cc, 2), F32, dev)
+        dgb = _empty((Cc, 2), F32, dev)
+        dx = torch.empty_like(x)
+        need_res = res is not None and ctx.needs_input_grad[1]
+        dres = torch.empty_like(x) if need_res else None
+        check(lib().dtt_bn_act_bwd(ptr(x), ptr(res), ptr(dz), ptr(stats), ptr(gamma), ptr(beta), ptr(part), ptr(sums),
+                                   ptr(dgb), ptr(dx), ptr(dres), P, Cc, act, 1 if training else 0, d, stream_ptr()),
+              "dtt_bn_act_bwd")
+        return dx, dres, dgb[:, 0].contiguous(), dgb[:, 1].contiguous(), None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, act, res=None):
+    """``bn``: an nn.BatchNorm2d (parameter / buffer container; its train()/eval() mode is honoured)."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    use_batch = bn.training or not bn.track_running_stats
+    return BatchNormAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, act)

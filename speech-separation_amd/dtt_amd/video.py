@@ -16,6 +16,7 @@ from torch import nn
 
 
 _NATIVE_BN = os.environ.get("DTT_VIDEO_NATIVE_BN", "1") == "1"
+_FUSED_BN = os.environ.get("DTT_VIDEO_FUSED_BN", "1") == "1"      # 0: ATen BatchNorm + elementwise Swish (A/B switch)
 
 
 class _NativeBN:
@@ -57,10 +58,17 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        r = x if self.downsample is None else self.downsample(x)
-        y = self.relu1(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        return self.relu2(y + r)
+        if not (_FUSED_BN and x.is_cuda):
+            r = x if self.downsample is None else self.downsample(x)
+            y = self.relu1(self.bn1(self.conv1(x)))
+            y = self.bn2(self.conv2(y))
+            return self.relu2(y + r)
+        # BatchNorm + Swish (+ residual) as ONE HIP pass forward and two backward (ops.BatchNormAct): the
+        # convolutions stay MIOpen's, everything between them is ours
+        from .ops import batch_norm_act
+        r = x if self.downsample is None else batch_norm_act(self.downsample[0](x), self.downsample[1], 0)
+        y = batch_norm_act(self.conv1(x), self.bn1, 1)
+        return batch_norm_act(self.conv2(y), self.bn2, 1, res=r)
 
 
 class ResNet18Trunk(nn.Module):

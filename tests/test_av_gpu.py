@@ -256,3 +256,46 @@ def test_pit_three_sources_vs_oracle():
     v = dtt_amd.SiSnrIPITInference()(audio=audio.to(DEV), preds=dp, sources=dsrc)
     r = oracle.pit_metric_inference(oracle.si_snr_i, audio, cp, sources)
     assert abs(float(v) - float(r)) < 0.05
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_fused_batchnorm_swish_blocks_against_aten(dt, tol):
+    """The lip encoder's residual blocks with BatchNorm + Swish (+ residual) on the HIP kernels (ops.BatchNormAct)
+    against the same blocks on ATen's batch_norm / sigmoid / mul (the path test_resnet18_video_encoder pins to the
+    reference): outputs, input and parameter gradients, running statistics; train and eval mode."""
+    from dtt_amd import video
+    torch.manual_seed(3)
+    blocks = torch.nn.Sequential(video.BasicBlock(64, 64), video.BasicBlock(64, 128, 2, torch.nn.Sequential(
+        torch.nn.Conv2d(64, 128, 1, stride=2, bias=False), video.BatchNorm2d(128)))).to(DEV)
+    for m in blocks.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    x0 = torch.randn(6, 64, 11, 9, device=DEV)
+    gy = torch.randn(6, 128, 6, 5, device=DEV)
+    state0 = {k: v.clone() for k, v in blocks.state_dict().items()}
+
+    def run(fused, train):
+        blocks.load_state_dict(state0)
+        blocks.train(train)
+        blocks.zero_grad()
+        video._FUSED_BN = fused
+        x = x0.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+            y = blocks(x)
+        y.float().backward(gy)
+        return (y.float().detach(), x.grad.clone(), {k: p.grad.clone() for k, p in blocks.named_parameters()},
+                {k: v.clone() for k, v in blocks.state_dict().items() if "running" in k or "tracked" in k})
+
+    try:
+        for train in (True, False):
+            ya, gxa, ga, ra = run(False, train)
+            yf, gxf, gf, rf = run(True, train)
+            assert rel_err(yf, ya) < tol, train
+            assert rel_err(gxf, gxa) < 2 * tol, train
+            for k in ga:
+                assert grad_close(gf[k], ga[k], 2 * tol, atol=1e-5 if dt == torch.float32 else 2e-2), (k, train)
+            for k in ra:
+                assert rel_err(rf[k].float(), ra[k].float()) < (1e-5 if dt == torch.float32 else 1e-2), (k, train)
+    finally:
+        video._FUSED_BN = True

@@ -237,11 +237,12 @@ int dtt_bcat_bwd(const void* dout, const float* dtok, void* dx, float* denh, int
 /* BatchNorm (+ residual) + activation on channels-last [P pixels][C] tensors, for the lip encoders on the
  * audio-visual path (VideoEncoders/resnet.py:36-81: bn -> swish; bn -> + residual -> swish; downsample bn;
  * resnet_video_encoder.py:40-44).  z = act(gamma * (x - mean) * rstd + beta (+ res)); act: 0 none, 1 swish, 2 relu.
- * stats [C][2] = {mean, rstd}: batch statistics from dtt_in_stats(B = 1) in training, dtt_bn_frozen_stats(running
+ * stats [C][2] = {mean, rstd}: batch statistics from dtt_bn_stats in training, dtt_bn_frozen_stats(running
  * buffers) in eval.  Backward recomputes the activation input from x (and res): dx, dres (= gradient at the
  * activation input; may be NULL), dgb [C][2] = {dgamma, dbeta}; partial: dtt_bn_chunks(P) * C * 2 floats, sums
  * [C][2] floats of scratch.  dtt_bn_running: nn.BatchNorm's running-statistics update (unbiased variance). */
 int dtt_bn_chunks(int P);
+int dtt_bn_stats(const void* x, float* partial, float* stats, int P, int C, float eps, int dtype, void* stream);
 int dtt_bn_act_fwd(const void* x, const void* res, const float* stats, const float* gamma, const float* beta, void* z,
                    int P, int C, int act, int dtype, void* stream);
 int dtt_bn_act_bwd(const void* x, const void* res, const void* dz, const float* stats, const float* gamma,
@@ -251,6 +252,13 @@ int dtt_bn_running(const float* stats, float* running_mean, float* running_var, 
                    float eps, void* stream);
 int dtt_bn_frozen_stats(const float* running_mean, const float* running_var, float* stats, int C, float eps,
                         void* stream);
+
+/* MaxPool 3x3 / stride 2 / padding 1 on channels-last [N][H][W][C]: the spatial part of the lip encoders'
+ * MaxPool3d((1,3,3),(1,2,2),(0,1,1)) (resnet_video_encoder.py:44, lipreading/model.py:132).  idx: one byte per output
+ * element (window position of the first maximum, ATen's choice); backward gathers (no atomics). */
+int dtt_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int dtype, void* stream);
+int dtt_maxpool3x3s2_bwd(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C, int dtype,
+                         void* stream);
 
 /* Gradient clip + AdamW over a table of fp32 tensors in two launches (the step after the hot path:
  * torch.optim.AdamW of train.yaml:20-23 after clip_grad_norm_ of base_trainer.py:478-490, train.yaml:59).

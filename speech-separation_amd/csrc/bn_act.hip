@@ -5,6 +5,7 @@
 // chunk with its per-channel constants in registers and walks pixels with four loads in flight; reductions are
 // two-stage and deterministic.  Statistics {mean, rstd} come from dtt_in_stats (B = 1: the whole batch is one
 // plane).  The activation input is recomputed in backward from x (and the residual), so nothing but x is saved.
+#include <algorithm>
 #include "common.h"
 #include "../../include/dtt_hip.h"
 
@@ -89,6 +90,82 @@ __device__ __forceinline__ void reduce_ch(const float (&v)[EPT], float* red, flo
         out[c] = s;
     }
     __syncthreads();
+}
+
+// batch statistics, pass 1: partial[chunk][C][2] = {mean, M2} of the chunk's pixels (second sweep is L2-hot)
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_stats_partial(const T* __restrict__ x, float* __restrict__ partial, int P, int C,
+                                                       int chunk) {
+    constexpr int EPT = Vec16<T>::N;
+    extern __shared__ float sm[];
+    float* red = sm;
+    float* chv = sm + NT * EPT;
+    const int cpp = C / EPT, ppi = NT / cpp, nact = ppi * cpp;
+    const int tid = threadIdx.x, pl = tid / cpp, cq = tid % cpp;
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    const T* base = x + cq * EPT;
+    float acc[EPT], mean[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
+    if (tid < nact)
+        for (int p = p0 + pl; p < p1; p += ppi) {
+            const Vec16<T> v = ld16<T>(base + (int64_t)p * C);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) acc[e] += v.get(e);
+        }
+    reduce_ch<EPT>(acc, red, chv, cpp, nact, C);
+    const float inv = 1.f / (float)(p1 - p0);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { mean[e] = chv[cq * EPT + e] * inv; acc[e] = 0.f; }
+    if (tid < nact)
+        for (int p = p0 + pl; p < p1; p += ppi) {
+            const Vec16<T> v = ld16<T>(base + (int64_t)p * C);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) { const float d = v.get(e) - mean[e]; acc[e] += d * d; }
+        }
+    float* dst = partial + ((int64_t)blockIdx.x * C) * 2;
+    if (tid < cpp)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) dst[(cq * EPT + e) * 2] = mean[e];
+    reduce_ch<EPT>(acc, red, chv, cpp, nact, C);
+    for (int c = tid; c < C; c += NT) dst[c * 2 + 1] = chv[c];
+}
+
+// pass 2: Chan merge of the chunk partials, 8 lane groups per channel each walking every eighth chunk, then a
+// fixed-order merge of the 8 (a single serial walk over ~500 chunks per channel cost 270 us per BatchNorm);
+// stats[c] = {mean, rstd}
+__global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ partial, float* __restrict__ stats, int P,
+                                                         int C, int chunk, int nchunks, float eps) {
+    __shared__ float sh[3][8][33];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < C)
+        for (int k = g; k < nchunks; k += 8) {
+            const float2 s = *reinterpret_cast<const float2*>(partial + ((int64_t)k * C + c) * 2);
+            const float nb = (float)(min(P, (k + 1) * chunk) - k * chunk);
+            const float d = s.x - mean, nn = n + nb;
+            mean += d * nb / nn;
+            m2 += s.y + d * d * n * nb / nn;
+            n = nn;
+        }
+    sh[0][g][cl] = n; sh[1][g][cl] = mean; sh[2][g][cl] = m2;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float tn = 0.f, tm = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float nb = sh[0][i][cl];
+            if (nb > 0.f) {
+                const float d = sh[1][i][cl] - tm, nn = tn + nb;
+                tm += d * nb / nn;
+                t2 += sh[2][i][cl] + d * d * tn * nb / nn;
+                tn = nn;
+            }
+        }
+        stats[c * 2] = tm;
+        stats[c * 2 + 1] = rsqrtf(t2 / tn + eps);
+    }
 }
 
 // pass 1: partial[chunk][C][2] = {sum da, sum da * xhat},  da = dz * act'(gamma * xhat + beta (+ res))
@@ -244,9 +321,95 @@ __global__ void bn_frozen_stats_kernel(const float* __restrict__ rmean, const fl
     stats[c * 2 + 1] = rsqrtf(rvar[c] + eps);
 }
 
+// ---------------------------------------------------------------------------------------------
+// MaxPool 3x3, stride 2, padding 1 on channels-last [N][H][W][C] (the spatial part of the lip encoders'
+// MaxPool3d((1,3,3),(1,2,2),(0,1,1)), resnet_video_encoder.py:44).  The window position of the maximum (first
+// maximum in (kh, kw) scan order, as ATen picks it) is kept as one byte per output element; backward is a gather
+// over the <= 4 windows that cover an input pixel: no atomics, deterministic.
+template <typename T>
+__global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                         unsigned char* __restrict__ idx, int N, int H, int W, int C,
+                                                         int Ho, int Wo) {
+    constexpr int EPT = Vec16<T>::N;
+    const int cpp = C / EPT;
+    const int64_t total = (int64_t)N * Ho * Wo * cpp;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int cq = (int)(i % cpp);
+        int64_t q = i / cpp;
+        const int wo = (int)(q % Wo); q /= Wo;
+        const int ho = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        float best[EPT];
+        unsigned char bi[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { best[e] = -INFINITY; bi[e] = 4; }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int h = 2 * ho - 1 + kh, w = 2 * wo - 1 + kw;
+                if (h < 0 || h >= H || w < 0 || w >= W) continue;
+                const Vec16<T> v = ld16<T>(x + (((int64_t)n * H + h) * W + w) * C + cq * EPT);
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const float f = v.get(e);
+                    if (f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(kh * 3 + kw); }
+                }
+            }
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) o.set(e, best[e]);
+        const int64_t ob = (((int64_t)n * Ho + ho) * Wo + wo) * C + cq * EPT;
+        st16<T>(y + ob, o);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) idx[ob + e] = bi[e];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                         T* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+    constexpr int EPT = Vec16<T>::N;
+    const int cpp = C / EPT;
+    const int64_t total = (int64_t)N * H * W * cpp;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int cq = (int)(i % cpp);
+        int64_t q = i / cpp;
+        const int w = (int)(q % W); q /= W;
+        const int h = (int)(q % H);
+        const int n = (int)(q / H);
+        float acc[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
+        // windows (ho, wo) with 2*ho - 1 + kh == h: ho in {(h+1)/2 (kh = h+1-2ho), ...}
+        for (int ho = (h + 1) / 2; ho >= 0 && 2 * ho - 1 <= h; --ho) {
+            const int kh = h + 1 - 2 * ho;
+            if (kh > 2) break;
+            if (ho >= Ho) continue;
+            for (int wo = (w + 1) / 2; wo >= 0 && 2 * wo - 1 <= w; --wo) {
+                const int kw = w + 1 - 2 * wo;
+                if (kw > 2) break;
+                if (wo >= Wo) continue;
+                const int64_t ob = (((int64_t)n * Ho + ho) * Wo + wo) * C + cq * EPT;
+                const Vec16<T> g = ld16<T>(dy + ob);
+                const unsigned char want = (unsigned char)(kh * 3 + kw);
+                unsigned char ib[EPT];
+                if (EPT == 8) *reinterpret_cast<uint2*>(ib) = *reinterpret_cast<const uint2*>(idx + ob);
+                else *reinterpret_cast<uint32_t*>(ib) = *reinterpret_cast<const uint32_t*>(idx + ob);
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) acc[e] += ib[e] == want ? g.get(e) : 0.f;
+            }
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) o.set(e, acc[e]);
+        st16<T>(dx + (((int64_t)n * H + h) * W + w) * C + cq * EPT, o);
+    }
+}
+
 int bn_chunk(int P) {
     int nch = P / 64;
-    if (nch > 2048) nch = 2048;
+    if (nch > 512) nch = 512;                               // ~2 workgroups per CU; the merges walk nch / 8 partials
     if (nch < 1) nch = 1;
     return (P + nch - 1) / nch;
 }
@@ -259,6 +422,21 @@ extern "C" int dtt_bn_chunks(int P) { const int ch = bn_chunk(P); return (P + ch
 static int bn_check(int P, int C, int dtype, const char* what) {
     const int ept = dtype ? 8 : 4;
     DTT_CHECK(P > 0 && C > 0 && C % ept == 0 && C / ept <= NT, "%s: C=%d must be a multiple of %d and at most %d", what, C, ept, NT * ept);
+    return 0;
+}
+
+// Batch statistics over all P pixels: stats [C][2] = {mean, rstd} (biased variance + eps, as nn.BatchNorm normalises);
+// partial: dtt_bn_chunks(P) * C * 2 floats of scratch.
+extern "C" int dtt_bn_stats(const void* x, float* partial, float* stats, int P, int C, float eps, int dtype, void* stream) {
+    if (int rc = bn_check(P, C, dtype, "dtt_bn_stats")) return rc;
+    DTT_CHECK(x && partial && stats, "dtt_bn_stats: bad arguments");
+    const int chunk = bn_chunk(P), nch = (P + chunk - 1) / chunk;
+    const int ept = dtype ? 8 : 4;
+    const size_t sm = (size_t)(NT * ept + C) * sizeof(float);
+    if (dtype) hipLaunchKernelGGL(bn_stats_partial<bf16>, dim3(nch), dim3(NT), sm, ST, (const bf16*)x, partial, P, C, chunk);
+    else hipLaunchKernelGGL(bn_stats_partial<float>, dim3(nch), dim3(NT), sm, ST, (const float*)x, partial, P, C, chunk);
+    hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 31) / 32), dim3(256), 0, ST, partial, stats, P, C, chunk, nch, eps);
+    DTT_LAUNCH_CHECK();
     return 0;
 }
 
@@ -310,6 +488,34 @@ extern "C" int dtt_bn_frozen_stats(const float* running_mean, const float* runni
                                    void* stream) {
     DTT_CHECK(stats && running_mean && running_var && C > 0, "dtt_bn_frozen_stats: bad arguments");
     hipLaunchKernelGGL(bn_frozen_stats_kernel, dim3((C + 127) / 128), dim3(128), 0, ST, running_mean, running_var, stats, C, eps);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+// MaxPool 3x3 / stride 2 / padding 1 on channels-last [N][H][W][C]; idx: one byte per output element (window
+// position of the maximum), Ho = (H - 1) / 2 + 1, Wo likewise.
+extern "C" int dtt_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int dtype,
+                                    void* stream) {
+    const int ept = dtype ? 8 : 4;
+    DTT_CHECK(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % ept == 0, "dtt_maxpool3x3s2_fwd: bad arguments (C=%d)", C);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / ept);
+    const int grid = (int)std::min<int64_t>((total + NT - 1) / NT, 65536);
+    if (dtype) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)x, (bf16*)y, idx, N, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(NT), 0, ST, (const float*)x, (float*)y, idx, N, H, W, C, Ho, Wo);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_maxpool3x3s2_bwd(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C, int dtype,
+                                    void* stream) {
+    const int ept = dtype ? 8 : 4;
+    DTT_CHECK(dy && dx && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % ept == 0, "dtt_maxpool3x3s2_bwd: bad arguments (C=%d)", C);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)N * H * W * (C / ept);
+    const int grid = (int)std::min<int64_t>((total + NT - 1) / NT, 65536);
+    if (dtype) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)dy, idx, (bf16*)dx, N, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(NT), 0, ST, (const float*)dy, idx, (float*)dx, N, H, W, C, Ho, Wo);
     DTT_LAUNCH_CHECK();
     return 0;
 }

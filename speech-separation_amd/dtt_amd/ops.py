@@ -1000,10 +1000,9 @@ class BatchNormAct(torch.autograd.Function):
         d, dev = _dt(x), x.device
         stats = _empty((Cc, 2), F32, dev)
         if training:
-            chunk = _in_chunk(1, P)
-            part = _empty((1, (P + chunk - 1) // chunk, Cc, 2), F32, dev)
-            check(lib().dtt_in_stats(ptr(x), ptr(part), ptr(stats), 1, P, Cc, chunk, C.c_float(eps), d, stream_ptr()),
-                  "dtt_in_stats")
+            part = _empty((lib().dtt_bn_chunks(P), Cc, 2), F32, dev)
+            check(lib().dtt_bn_stats(ptr(x), ptr(part), ptr(stats), P, Cc, C.c_float(eps), d, stream_ptr()),
+                  "dtt_bn_stats")
             if rmean is not None:
                 check(lib().dtt_bn_running(ptr(stats), ptr(rmean), ptr(rvar), Cc, C.c_int64(P), C.c_float(momentum),
                                            C.c_float(eps), stream_ptr()), "dtt_bn_running")
@@ -1045,3 +1044,31 @@ def batch_norm_act(x, bn, act, res=None):
     mom = 0.1 if bn.momentum is None else bn.momentum
     use_batch = bn.training or not bn.track_running_stats
     return BatchNormAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, act)
+
+
+class MaxPool3x3s2(torch.autograd.Function):
+    """max_pool2d(x, 3, 2, 1) on an NCHW tensor in channels-last memory (the per-frame form of the lip encoders'
+    MaxPool3d((1,3,3),(1,2,2),(0,1,1)))."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous(memory_format=torch.channels_last)
+        Nb, Cc, Hh, Ww = x.shape
+        Ho, Wo = (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1
+        y = torch.empty((Nb, Cc, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((Nb, Ho, Wo, Cc), dtype=torch.uint8, device=x.device)
+        check(lib().dtt_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(idx), Nb, Hh, Ww, Cc, _dt(x), stream_ptr()),
+              "dtt_maxpool3x3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (Nb, Cc, Hh, Ww)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        Nb, Cc, Hh, Ww = ctx.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((Nb, Cc, Hh, Ww), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        check(lib().dtt_maxpool3x3s2_bwd(ptr(dy), ptr(idx), ptr(dx), Nb, Hh, Ww, Cc, _dt(dy), stream_ptr()),
+              "dtt_maxpool3x3s2_bwd")
+        return dx

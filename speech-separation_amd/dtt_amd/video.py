@@ -120,12 +120,37 @@ class VideoEncoder(nn.Module):
             ck = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
             self.load_state_dict(ck["model_state_dict"], strict=False)
 
+    def _frontend_fused(self, x):
+        """frontend3D on the HIP path.  With one input channel, Conv3d((5,7,7), stride (1,2,2), padding (2,3,3)) is a
+        per-frame Conv2d over the 5 neighbouring frames stacked as channels (zero frames beyond the clip's ends), so
+        its output is born as [frames, 64, 44, 44] in channels-last memory: no im2col of a 3-d volume, no layout
+        change towards the 2-d trunk.  BatchNorm3d's statistics over (N, D, H, W) are BatchNorm2d's over
+        (N * D, H, W); BN + Swish and the (1,3,3) max pool run on the fused kernels."""
+        from .ops import batch_norm_act, MaxPool3x3s2
+        conv, bn = self.frontend3D[0], self.frontend3D[1]
+        Bp, _, T, H, W = x.shape
+        kt = conv.kernel_size[0]
+        xp = nn.functional.pad(x[:, 0], (0, 0, 0, 0, kt // 2, kt // 2))            # [B', T + 4, H, W]
+        x5 = xp.unfold(1, kt, 1).permute(0, 1, 4, 2, 3).reshape(Bp * T, kt, H, W)   # frames t-2 .. t+2 as channels
+        w2 = conv.weight[:, 0]                                                    # [64, 5, 7, 7]
+        cpad = (-kt) % 8                                                          # channel count to a multiple of 8
+        if cpad:
+            x5 = nn.functional.pad(x5, (0, 0, 0, 0, 0, cpad))
+            w2 = nn.functional.pad(w2, (0, 0, 0, 0, 0, cpad))
+        x5 = x5.contiguous(memory_format=torch.channels_last)
+        y = nn.functional.conv2d(x5, w2, None, stride=conv.stride[1:], padding=conv.padding[1:])
+        y = batch_norm_act(y, bn, 1)
+        return MaxPool3x3s2.apply(y), T
+
     def forward(self, x):
         B, N, T, H, W = x.shape
-        x = self.frontend3D(x.reshape(B * N, 1, T, H, W))
-        Tn = x.shape[2]
-        x = x.transpose(1, 2).reshape(B * N * Tn, x.shape[1], x.shape[3], x.shape[4])
-        x = x.contiguous(memory_format=torch.channels_last)
+        if _FUSED_BN and x.is_cuda:
+            x, Tn = self._frontend_fused(x.reshape(B * N, 1, T, H, W))
+        else:
+            x = self.frontend3D(x.reshape(B * N, 1, T, H, W))
+            Tn = x.shape[2]
+            x = x.transpose(1, 2).reshape(B * N * Tn, x.shape[1], x.shape[3], x.shape[4])
+            x = x.contiguous(memory_format=torch.channels_last)
         x = self.trunk(x)
         return x.view(B, N, Tn, -1).transpose(2, 3)
 

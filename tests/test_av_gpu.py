@@ -299,3 +299,44 @@ def test_fused_batchnorm_swish_blocks_against_aten(dt, tol):
                 assert rel_err(rf[k].float(), ra[k].float()) < (1e-5 if dt == torch.float32 else 1e-2), (k, train)
     finally:
         video._FUSED_BN = True
+
+
+def test_fused_frontend_and_maxpool_against_aten():
+    """VideoEncoder with the frontend on the HIP path (Conv3d as a per-frame Conv2d over stacked frames, fused
+    BatchNorm + Swish, channels-last max pool) against the stock Conv3d / BatchNorm3d / MaxPool3d modules: output
+    and every parameter gradient, fp32, train mode; plus the max pool alone against F.max_pool2d incl. bf16 ties."""
+    from dtt_amd import video, ops
+    fx_sd = fill_state_dict(load_manifest("resnet18"), 8)
+    enc = video.VideoEncoder().to(DEV)
+    enc.load_state_dict(fx_sd)
+    vid = synth_video(1, 5, seed=19).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    gy = torch.randn(1, 2, 512, 5, generator=g).to(DEV)
+    outs = {}
+    try:
+        for fused in (False, True):
+            video._FUSED_BN = fused
+            enc.load_state_dict(fx_sd)
+            enc.train()
+            enc.zero_grad()
+            y = enc(vid)
+            y.backward(gy)
+            outs[fused] = (y.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters()},
+                           {k: v.clone() for k, v in enc.state_dict().items() if "running" in k})
+    finally:
+        video._FUSED_BN = True
+    assert rel_err(outs[True][0], outs[False][0]) < 2e-4
+    for k, gr in outs[False][1].items():
+        assert grad_close(outs[True][1][k], gr, 2e-3, atol=1e-6 * float(gr.abs().max()) + 1e-9), k
+    for k, v in outs[False][2].items():
+        assert rel_err(outs[True][2][k], v) < 1e-4, k
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(3, 16, 11, 14, generator=g).to(DEV).to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        xr = x.detach().clone().requires_grad_(True)
+        y = ops.MaxPool3x3s2.apply(x)
+        yr = F.max_pool2d(xr, 3, 2, 1)
+        assert torch.equal(y, yr)
+        gg = torch.randn(yr.shape, generator=g).to(DEV).to(dt)
+        y.backward(gg)
+        yr.backward(gg)
+        assert rel_err(x.grad.float(), xr.grad.float()) < (1e-6 if dt == torch.float32 else 2e-2)

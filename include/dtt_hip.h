@@ -234,6 +234,15 @@ int dtt_bcat_fwd(const void* x, const float* enh, void* out, int B, int F, int T
 int dtt_bcat_bwd(const void* dout, const float* dtok, void* dx, float* denh, int B, int F, int T, int C, int dtype,
                  void* stream);
 
+/* Cross-attention core of CrossAttentionPositional (cross_attention_positional.py:66-69: nn.MultiheadAttention
+ * behind its input projections): out = softmax(scale * q k^T) v per head, fp32, exact-fp32 MFMA tiles, one
+ * workgroup per (item, head).  q [B][Tq][C], k, v [B][Tk][C], prob [B][heads][Tq][Tk] (kept for backward);
+ * Tq <= 32, Tk <= 160, head width a multiple of 32. */
+int dtt_xattn_fwd(const float* q, const float* k, const float* v, float* out, float* prob, int B, int Tq, int Tk, int C,
+                  int heads, float scale, void* stream);
+int dtt_xattn_bwd(const float* q, const float* k, const float* v, const float* prob, const float* dout, float* dq,
+                  float* dk, float* dv, int B, int Tq, int Tk, int C, int heads, float scale, void* stream);
+
 /* BatchNorm (+ residual) + activation on channels-last [P pixels][C] tensors, for the lip encoders on the
  * audio-visual path (VideoEncoders/resnet.py:36-81: bn -> swish; bn -> + residual -> swish; downsample bn;
  * resnet_video_encoder.py:40-44).  z = act(gamma * (x - mean) * rstd + beta (+ res)); act: 0 none, 1 swish, 2 relu.

@@ -8,7 +8,8 @@ from .metrics import (SiSnr, SiSnrI, SiSnrPITTraining, SiSnrPITInference, SiSnrI
                       SiSnrIPITInference)
 from .ops import stft_mag_phase  # noqa: F401
 from .optim import ClipAdamW  # noqa: F401
-from .io import load_reference_checkpoint, save_reference_checkpoint, align_state_dict_keys  # noqa: F401
-from .feeder import collate_on_device  # noqa: F401
+from .io import (load_reference_checkpoint, save_reference_checkpoint, align_state_dict_keys,  # noqa: F401
+                 write_wav_float32, save_separated)
+from .feeder import collate_on_device, spec_augment_on_device  # noqa: F401
 from .graph import GraphedTrainStep  # noqa: F401
 from .dist import GradBucketReducer  # noqa: F401

@@ -87,3 +87,34 @@ def collate_on_device(dataset_items, device, n_fft=1024, hop_length=256):
         else:
             batch["video"] = v.float().to(device, non_blocking=True)
     return batch
+
+
+def spec_augment_on_device(x, p=0.9, time_drop_width=16, time_stripes_num=2, freq_drop_width=16, freq_stripes_num=2,
+                           generator=None):
+    """SpecAugment stripes on a batch already on the GPU.
+
+    Reference: src/transforms/spec_augs/spec_augmentation.py:7-17 wraps torchlibrosa.augmentation.SpecAugmentation
+    (torchlibrosa is a third-party dependency, not vendored and not installed here: its published algorithm is
+    restated, parity unpinned) and the data loader applies it per item, independently to ``spectrogram`` and
+    ``phase`` (instance_transforms/baseline.yaml:49-64), with probability ``p``.  torchlibrosa's DropStripes draws,
+    per item and stripe, ``distance = randint(0, drop_width)`` and ``bgn = randint(0, width - distance)`` and zeroes
+    ``[bgn, bgn + distance)``; its "time" axis is dim 2 and its "freq" axis dim 3 of a [B, 1, *, *] tensor, which for
+    the reference's [1, F, T] items are F and T respectively (kept as is: parity is with the reference's behaviour).
+
+    x [B, F, T] -> augmented copy.  All draws come from ``generator`` on x's device: no host synchronisation."""
+    B, Fq, T = x.shape
+    dev = x.device
+
+    def keep_mask(width, drop_width, stripes):
+        keep = torch.ones(B, width, dtype=torch.bool, device=dev)
+        pos = torch.arange(width, device=dev).unsqueeze(0)
+        for _ in range(stripes):
+            dist = torch.floor(torch.rand(B, 1, device=dev, generator=generator) * drop_width)          # [0, drop_width)
+            bgn = torch.floor(torch.rand(B, 1, device=dev, generator=generator) * (width - dist).clamp(min=1))
+            keep &= ~((pos >= bgn) & (pos < bgn + dist))
+        return keep
+
+    apply = torch.rand(B, 1, 1, device=dev, generator=generator) <= p
+    kf = keep_mask(Fq, time_drop_width, time_stripes_num).unsqueeze(2)        # torchlibrosa's dim 2 = our F axis
+    kt = keep_mask(T, freq_drop_width, freq_stripes_num).unsqueeze(1)         # torchlibrosa's dim 3 = our T axis
+    return torch.where(apply & ~(kf & kt), torch.zeros((), dtype=x.dtype, device=dev), x)

@@ -48,29 +48,40 @@ class CrossAttentionPositional(nn.Module):
         self.audio_gate = nn.Sequential(nn.Linear(audio_channels, audio_channels), nn.Sigmoid())
 
     def _tokens(self, a, video):
-        """Token-level network in fp32 (autocast disabled: tiny, keep it exact)."""
+        """Token-level network in fp32 (outside autocast: 16 + 50 tokens per item).  Every Linear runs through
+        dtt_gemm (ops.Linear: exact-fp32 MFMA, fused bias / sigmoid), the attention core on the MFMA tile kernel
+        (ops.CrossAttnCore); LayerNorm, GELU and the residual adds are elementwise torch ops on [B, <= 150, C]."""
+        lin = ops.Linear.apply
         B, T, Cc = a.shape
         _, Cv, Ev, Tv = video.shape
         v = video.float().permute(0, 3, 1, 2).reshape(B, Tv, Cv * Ev)
-        v = F.gelu(F.linear(v, self.video_proj[0].weight, self.video_proj[0].bias))
+        v = F.gelu(lin(v, self.video_proj[0].weight, self.video_proj[0].bias, False))
         a = a + _build_sinusoids(T, Cc, a.device).unsqueeze(0)
         v = v + _build_sinusoids(Tv, Cc, a.device).unsqueeze(0)
         ln = self.inp_layernorm
-        q = self.q_audio(F.layer_norm(a, (Cc,), ln.weight, ln.bias, ln.eps))
+        q = lin(F.layer_norm(a, (Cc,), ln.weight, ln.bias, ln.eps), self.q_audio.weight, self.q_audio.bias, False)
         vn = F.layer_norm(v, (Cc,), ln.weight, ln.bias, ln.eps)
-        k, vv = self.k_video(vn), self.v_video(vn)
+        k = lin(vn, self.k_video.weight, self.k_video.bias, False)
+        vv = lin(vn, self.v_video.weight, self.v_video.bias, False)
         ca = self.cross_attn
-        H, dh = self.n_heads, Cc // self.n_heads
-        qp = F.linear(q, ca.in_proj_weight[:Cc], ca.in_proj_bias[:Cc]).view(B, T, H, dh).transpose(1, 2)
-        kp = F.linear(k, ca.in_proj_weight[Cc:2 * Cc], ca.in_proj_bias[Cc:2 * Cc]).view(B, Tv, H, dh).transpose(1, 2)
-        vp = F.linear(vv, ca.in_proj_weight[2 * Cc:], ca.in_proj_bias[2 * Cc:]).view(B, Tv, H, dh).transpose(1, 2)
-        att = torch.softmax(qp @ kp.transpose(-1, -2) / math.sqrt(dh), dim=-1)
-        o = (att @ vp).transpose(1, 2).reshape(B, T, Cc)
-        o = F.linear(o, ca.out_proj.weight, ca.out_proj.bias)
+        qp = lin(q, ca.in_proj_weight[:Cc], ca.in_proj_bias[:Cc], False)
+        kp = lin(k, ca.in_proj_weight[Cc:2 * Cc], ca.in_proj_bias[Cc:2 * Cc], False)
+        vp = lin(vv, ca.in_proj_weight[2 * Cc:], ca.in_proj_bias[2 * Cc:], False)
+        dh = Cc // self.n_heads
+        if dh % 32 == 0 and T <= 32 and Tv <= 160:
+            o = ops.CrossAttnCore.apply(qp, kp, vp, self.n_heads)
+        else:                                   # head widths / token counts the tile kernel does not cover
+            H = self.n_heads
+            att = torch.softmax(qp.view(B, T, H, dh).transpose(1, 2) @ kp.view(B, Tv, H, dh).permute(0, 2, 3, 1)
+                                / math.sqrt(dh), dim=-1)
+            o = (att @ vp.view(B, Tv, H, dh).transpose(1, 2)).transpose(1, 2).reshape(B, T, Cc)
+        o = lin(o, ca.out_proj.weight, ca.out_proj.bias, False)
         al = self.attn_layernorm
         a = F.layer_norm(a + o, (Cc,), al.weight, al.bias, al.eps)
-        a = a + self.cross_ffn(a)
-        return a * self.audio_gate(a)
+        f = lin(F.gelu(lin(a, self.cross_ffn[0].weight, self.cross_ffn[0].bias, False)), self.cross_ffn[2].weight,
+                self.cross_ffn[2].bias, False)
+        a = a + f
+        return a * lin(a, self.audio_gate[0].weight, self.audio_gate[0].bias, True)
 
     def forward(self, audio_features, video_features):
         tok = ops.FreqMeanTokens.apply(audio_features)                 # [B,T,C] fp32

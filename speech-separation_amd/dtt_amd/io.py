@@ -59,3 +59,38 @@ def save_reference_checkpoint(path, model, epoch=0, optimizer=None, lr_scheduler
     }
     torch.save(state, path)
     return state
+
+
+def write_wav_float32(path, audio, sample_rate=16000):
+    """One mono/multi-channel float32 WAV (IEEE float, what ``torchaudio.save`` writes for a float32 tensor):
+    audio [L] or [channels, L]."""
+    import struct
+    a = torch.as_tensor(audio).detach().to("cpu", torch.float32)
+    if a.dim() == 1:
+        a = a.unsqueeze(0)
+    ch, n = a.shape
+    data = a.t().contiguous().numpy().tobytes()                # interleaved frames
+    fmt = struct.pack("<HHIIHH", 3, ch, sample_rate, sample_rate * ch * 4, ch * 4, 32)
+    fact = struct.pack("<I", n)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"fact" + struct.pack("<I", 4) + fact \
+        + b"data" + struct.pack("<I", len(data)) + data
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def save_separated(batch, save_dir, part="test", sample_rate=16000):
+    """Per-item dump of the separated sources (Inferencer.process_batch, src/trainer/inferencer.py:169-181):
+    ``<save_dir>/<part>/source_<k>/<stem of audio_path>.wav`` for every item and prediction.  One device-to-host
+    copy per prediction tensor (the reference copies item by item).  Returns the written paths."""
+    import os
+    out = []
+    preds = [p["audio"].detach().to("cpu", torch.float32) for p in batch["preds"]]
+    for i, src_path in enumerate(batch["audio_path"]):
+        stem = os.path.splitext(os.path.basename(str(src_path)))[0]
+        for k, a in enumerate(preds):
+            d = os.path.join(str(save_dir), part, f"source_{k}")
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, stem + ".wav")
+            write_wav_float32(path, a[i], sample_rate)
+            out.append(path)
+    return out

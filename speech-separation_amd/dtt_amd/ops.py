@@ -1072,3 +1072,69 @@ class MaxPool3x3s2(torch.autograd.Function):
         check(lib().dtt_maxpool3x3s2_bwd(ptr(dy), ptr(idx), ptr(dx), Nb, Hh, Ww, Cc, _dt(dy), stream_ptr()),
               "dtt_maxpool3x3s2_bwd")
         return dx
+
+
+# --------------------------------------------------------------------------- #
+# token network of the cross-attention fusion (cross_attention_positional.py:55-75)
+# --------------------------------------------------------------------------- #
+class Linear(torch.autograd.Function):
+    """y = x W^T + b through dtt_gemm (exact-fp32 MFMA for fp32 tokens), optional fused sigmoid (the audio gate,
+    cross_attention_positional.py:46-49); weight / bias gradients by split-K GEMM and deterministic column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, sigmoid):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        wt = w.to(x2.dtype).contiguous()
+        y = _empty((x2.shape[0], wt.shape[0]), x2.dtype, x2.device)
+        kw = dict(A=x2, B=wt, C=y, M=x2.shape[0], N=wt.shape[0], K=x2.shape[1], a_ms=x2.shape[1], a_ks=1, b_ks=1,
+                  b_ns=x2.shape[1], c_ms=wt.shape[0], c_ns=1, dtype=_dt(x2), act=2 if sigmoid else 0)
+        if b is not None:
+            kw.update(bias=b, bias_mode=1)
+        gemm_raw(**kw)
+        ctx.save_for_backward(x2, wt, y if sigmoid else None)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.view(x.shape[:-1] + (wt.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wt, y = ctx.saved_tensors
+        dy2 = dy.reshape(-1, wt.shape[0]).to(x2.dtype)
+        if y is not None:
+            dy2 = dy2 * (y * (1.0 - y))
+        dy2 = dy2.contiguous()
+        dx, dw = _linear_bwd(x2, wt, dy2, ctx.needs_input_grad[0])
+        db = colsum(dy2, dy2.shape[0], dy2.shape[1]) if ctx.has_bias else None
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None
+
+
+class CrossAttnCore(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh)) v per head on exact-fp32 MFMA tiles (attn.hip): the core of the reference's
+    nn.MultiheadAttention call (cross_attention_positional.py:66-69) behind its input projections.
+    q [B,Tq,C], k, v [B,Tk,C] fp32 -> [B,Tq,C]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        q, k, v = q.contiguous().float(), k.contiguous().float(), v.contiguous().float()
+        B, Tq, Cc = q.shape
+        Tk = k.shape[1]
+        scale = 1.0 / math.sqrt(Cc // heads)
+        out = _empty((B, Tq, Cc), F32, q.device)
+        prob = _empty((B, heads, Tq, Tk), F32, q.device)
+        check(lib().dtt_xattn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(prob), B, Tq, Tk, Cc, heads, C.c_float(scale),
+                                  stream_ptr()), "dtt_xattn_fwd")
+        ctx.save_for_backward(q, k, v, prob)
+        ctx.cfg = (heads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, prob = ctx.saved_tensors
+        heads, scale = ctx.cfg
+        B, Tq, Cc = q.shape
+        Tk = k.shape[1]
+        do = do.contiguous().float()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        check(lib().dtt_xattn_bwd(ptr(q), ptr(k), ptr(v), ptr(prob), ptr(do), ptr(dq), ptr(dk), ptr(dv), B, Tq, Tk, Cc,
+                                  heads, C.c_float(scale), stream_ptr()), "dtt_xattn_bwd")
+        return dq, dk, dv, None

@@ -93,3 +93,19 @@ def test_reference_checkpoint_interchange(tmp_path):
     assert missing == [key] and not unexpected and sorted(skipped) == sorted([key, "foreign_head.weight"])
     assert torch.equal(c.state_dict()[key], before)
     assert torch.equal(c.state_dict()["decoder.out_conv.weight"], a.state_dict()["decoder.out_conv.weight"])
+
+
+def test_per_item_wav_writer(tmp_path):
+    """Inferencer.process_batch's dump (inferencer.py:169-181): <dir>/<part>/source_<k>/<stem>.wav, float32 WAV."""
+    import dtt_amd
+    from scipy.io import wavfile
+    g = torch.Generator().manual_seed(0)
+    preds = [{"audio": torch.randn(3, 800, generator=g) * 0.1} for _ in range(2)]
+    batch = {"preds": preds, "audio_path": ["/data/a/mix_0.wav", "mix_1.flac", "dir/x.y.wav"]}
+    paths = dtt_amd.save_separated(batch, tmp_path, part="val", sample_rate=16000)
+    assert len(paths) == 6
+    for k in range(2):
+        for i, stem in enumerate(["mix_0", "mix_1", "x.y"]):
+            sr, data = wavfile.read(tmp_path / "val" / f"source_{k}" / f"{stem}.wav")
+            assert sr == 16000 and data.dtype == "float32" and data.shape == (800,)
+            assert torch.equal(torch.from_numpy(data.copy()), preds[k]["audio"][i])

@@ -340,3 +340,25 @@ def test_fused_frontend_and_maxpool_against_aten():
         y.backward(gg)
         yr.backward(gg)
         assert rel_err(x.grad.float(), xr.grad.float()) < (1e-6 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,Cc,heads", [(3, 16, 50, 512, 2), (2, 16, 150, 1024, 2), (2, 5, 7, 64, 2), (1, 32, 160, 128, 4)])
+def test_cross_attention_core_mfma_tiles(B, Tq, Tk, Cc, heads):
+    """ops.CrossAttnCore (attn.hip: exact-fp32 MFMA tiles, one workgroup per item and head) against
+    softmax(q k^T / sqrt(dh)) v in fp64 -- the arithmetic of nn.MultiheadAttention behind its projections
+    (cross_attention_positional.py:66-69) -- forward and the three input gradients, at the cfg4 / cfg5 sizes."""
+    from dtt_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + Tk)
+    q, k, v = (torch.randn(B, t, Cc, generator=g) for t in (Tq, Tk, Tk))
+    do = torch.randn(B, Tq, Cc, generator=g)
+    dh = Cc // heads
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    att = torch.softmax(qr.view(B, Tq, heads, dh).transpose(1, 2) @ kr.view(B, Tk, heads, dh).permute(0, 2, 3, 1) / dh ** 0.5, -1)
+    ref = (att @ vr.view(B, Tk, heads, dh).transpose(1, 2)).transpose(1, 2).reshape(B, Tq, Cc)
+    ref.backward(do.double())
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = ops.CrossAttnCore.apply(qd, kd, vd, heads)
+    assert rel_err(out, ref) < 1e-5
+    out.backward(do.to(DEV))
+    for a, b in ((qd, qr), (kd, kr), (vd, vr)):
+        assert rel_err(a.grad, b.grad) < 2e-5

@@ -74,3 +74,29 @@ def test_collated_batch_feeds_the_model():
     batch.update(model(**batch))
     res = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())(**batch)
     assert torch.isfinite(res["loss"]).item() and res["batch_permuts"].shape == (2, 2)
+
+
+def test_spec_augment_on_device_properties():
+    """On-device SpecAugment stripes (spec_augs/spec_augmentation.py:7-17 over torchlibrosa's DropStripes; the
+    library is absent: parity unpinned, its published algorithm restated).  Checked by what the algorithm guarantees:
+    only whole rows / columns are zeroed, at most stripes_num stripes per axis and item each narrower than
+    drop_width, everything else untouched, p = 0 is the identity, p = 1 touches every item, deterministic per seed."""
+    import dtt_amd
+    B, Fq, T = 8, 513, 126
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand(B, Fq, T, device=DEV) + 0.5                       # strictly positive: zeros are stripes
+    y = dtt_amd.spec_augment_on_device(x, p=1.0, generator=g)
+    z = (y == 0)
+    assert torch.equal(torch.where(z, x, y), x)                      # untouched elsewhere
+    for b in range(B):
+        rows = z[b].all(dim=1)                                       # zeroed F rows (torchlibrosa's "time" stripes)
+        cols = z[b].all(dim=0)
+        assert torch.equal(z[b], rows[:, None] | cols[None, :])      # only whole rows / columns
+        for v in (rows, cols):
+            d = torch.diff(torch.cat([torch.zeros(1, device=DEV), v.float(), torch.zeros(1, device=DEV)]))
+            starts, ends = (d == 1).nonzero().flatten(), (d == -1).nonzero().flatten()
+            assert len(starts) <= 2 and all(int(e - s) < 32 for s, e in zip(starts, ends))   # 2 stripes of < 16 may merge
+    assert torch.equal(dtt_amd.spec_augment_on_device(x, p=0.0, generator=g), x)
+    g1 = torch.Generator(device=DEV).manual_seed(9)
+    g2 = torch.Generator(device=DEV).manual_seed(9)
+    assert torch.equal(dtt_amd.spec_augment_on_device(x, generator=g1), dtt_amd.spec_augment_on_device(x, generator=g2))

@@ -187,3 +187,124 @@ class GradBucketReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+
+
+class ShardedClipAdamW:
+    """The optimizer step of the reference's loop (clip_grad_norm_ + AdamW, train.yaml:20-31,59, trainer.py:61-64)
+    sharded over the data-parallel ranks:
+
+        reduce-scatter(mean) of the flat gradient  ->  sum of squares of the local shard, all-reduce of ONE float
+        ->  dtt_clip_adamw_ex on the shard (global clip coefficient, AdamW with this rank's 1/W of the moments)
+        ->  all-gather of the updated flat parameters.
+
+    Against all-reduce + a replicated update this moves the same bytes over xGMI (reduce-scatter + all-gather = one
+    all-reduce) but touches 1/W of the parameter / moment bytes per GPU (206M parameters x (p, g, m, v) = 3.3 GB per
+    step at cfg5) and keeps 1/W of the optimizer state.  Parameters are re-pointed at views of one flat fp32 buffer
+    (padded to a multiple of 256 x world) so that the collectives run on whole buffers.
+
+    ``weight_decay_of(name) -> float`` gives the per-parameter decay (the reference: 0 for names containing "bias",
+    init_utils.py:63-80).  After step() ``p.grad`` still holds the LOCAL gradient; the averaged one exists only as
+    this rank's shard.  Checkpointing the moments needs a gather of ``state_shard()`` over the ranks."""
+
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, weight_decay_of=None,
+                 max_norm=None, process_group=None, force_collectives=False):
+        from .optim import ClipAdamW
+        self._force = force_collectives       # issue the collectives even in a one-rank group (single-GPU RCCL probe)
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        gran = 256 * self.world
+        self.n_pad = (n + gran - 1) // gran * gran
+        self.k = self.n_pad // self.world
+        self.flat_p = torch.zeros(self.n_pad, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(self.n_pad, dtype=torch.float32, device=dev)
+        self._host_staged = (self.world > 1 and dist.get_backend(process_group) == "gloo" and dev.type == "cuda")
+        offs, o = [], 0
+        with torch.no_grad():
+            for p in self.params:
+                self.flat_p[o:o + p.numel()].copy_(p.reshape(-1))
+                p.data = self.flat_p[o:o + p.numel()].view_as(p)
+                offs.append(o)
+                o += p.numel()
+        self.gviews = [self.flat_g[a:a + p.numel()].view_as(p) for a, p in zip(offs, self.params)]
+        lo, hi = self.rank * self.k, (self.rank + 1) * self.k
+        self.pshard = self.flat_p[lo:hi]
+        self.gshard = torch.zeros(self.k, dtype=torch.float32, device=dev)
+        groups = {}
+        self.segments = []                                    # (name, leaf view of the parameter shard, offset in gshard)
+        for (name, p), a in zip(named, offs):
+            s0, s1 = max(a, lo), min(a + p.numel(), hi)
+            if s0 >= s1:
+                continue
+            seg = self.flat_p[s0:s1].detach().requires_grad_(True)
+            wd = weight_decay if weight_decay_of is None else weight_decay_of(name)
+            groups.setdefault(float(wd), []).append(seg)
+            self.segments.append((name, seg, s0 - lo, s1 - lo))
+        if not self.segments:
+            raise RuntimeError("ShardedClipAdamW: this rank's shard is empty (fewer parameters than 256 x world)")
+        self.inner = ClipAdamW([{"params": ps, "weight_decay": wd} for wd, ps in groups.items()], lr=lr, betas=betas,
+                               eps=eps, max_norm=max_norm)
+        self.param_groups = self.inner.param_groups           # lr schedulers act on these
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def _reduce_scatter_mean(self):
+        if self.world == 1 and not self._force:
+            self.gshard.copy_(self.flat_g)
+            return
+        if self._host_staged or dist.get_backend(self.group) == "gloo":      # rehearsal path: gloo has no reduce-scatter
+            h = self.flat_g.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            self.gshard.copy_(h[self.rank * self.k:(self.rank + 1) * self.k] / self.world)
+            return
+        dist.reduce_scatter_tensor(self.gshard, self.flat_g, op=dist.ReduceOp.AVG, group=self.group)
+
+    def _all_reduce_sum(self, t):
+        if self.world == 1 and not self._force:
+            return t
+        if self._host_staged:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def _all_gather_params(self):
+        if self.world == 1 and not self._force:
+            return
+        if self._host_staged or dist.get_backend(self.group) == "gloo":
+            parts = [torch.empty(self.k) for _ in range(self.world)]
+            dist.all_gather(parts, self.pshard.cpu(), group=self.group)
+            self.flat_p.copy_(torch.cat(parts))
+            return
+        dist.all_gather_into_tensor(self.flat_p, self.pshard.clone(), group=self.group)
+
+    @torch.no_grad()
+    def step(self):
+        """Returns the global (unclipped) gradient norm as a 1-element device tensor when max_norm is set."""
+        have = [(v, p.grad) for v, p in zip(self.gviews, self.params) if p.grad is not None]
+        missing = [v for v, p in zip(self.gviews, self.params) if p.grad is None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v in missing:
+            v.zero_()
+        self._reduce_scatter_mean()
+        for _, seg, a, b in self.segments:
+            seg.grad = self.gshard[a:b]
+        ss = self._all_reduce_sum(self.inner.grad_sumsq())
+        out = self.inner.step(sumsq=ss)
+        self._all_gather_params()
+        return out
+
+    def state_shard(self):
+        """{parameter name: (offset of the segment in the flat parameter, exp_avg, exp_avg_sq)} of this rank."""
+        st = self.inner.state
+        return {name: (a + self.rank * self.k, st[seg]["exp_avg"], st[seg]["exp_avg_sq"])
+                for name, seg, a, _ in self.segments if seg in st}

@@ -115,9 +115,24 @@ class ClipAdamW(torch.optim.Optimizer):
             ptrs=[p.data_ptr() for p, _ in plist], checked=False)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def grad_sumsq(self):
+        """Sum of squares of the gradients this optimizer holds, as a 1-element device tensor (deterministic
+        two-stage reduction).  The sharded data-parallel step all-reduces it over the ranks and hands it back to
+        ``step(sumsq=...)``, so that every shard clips by the GLOBAL norm."""
+        if self._built is None:
+            self._build()
+        b = self._built
+        self._upload([0 if p.grad is None else p.grad.data_ptr() for p in b["params"]])
+        out = torch.zeros(1, dtype=torch.float32, device=b["m"].device)
+        check(lib().dtt_grad_sumsq(ptr(b["dev_tab"]), len(b["params"]), ptr(b["chunks"]), b["chunks"].shape[0],
+                                   ptr(b["partial"]), ptr(out), stream_ptr()), "dtt_grad_sumsq")
+        return out
+
+    @torch.no_grad()
+    def step(self, closure=None, sumsq=None):
         """One clipped AdamW update.  Returns the (unclipped) total gradient norm as a 1-element device
-        tensor when ``max_norm`` is set, else the closure's loss."""
+        tensor when ``max_norm`` is set, else the closure's loss.  ``sumsq`` (1-element fp32 device tensor):
+        externally merged squared norm (see grad_sumsq)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -153,7 +168,7 @@ class ClipAdamW(torch.optim.Optimizer):
         check(lib().dtt_clip_adamw_ex(ptr(b["dev_tab"]), len(b["params"]), ptr(b["chunks"]), b["chunks"].shape[0],
                                       ptr(b["partial"]), C.c_float(mx), C.c_float(g0["betas"][0]),
                                       C.c_float(g0["betas"][1]), C.c_float(g0["eps"]), self._step,
-                                      ptr(self._step_dev), None, C.c_float(self.grad_scale), ptr(b["norm"]),
+                                      ptr(self._step_dev), ptr(sumsq), C.c_float(self.grad_scale), ptr(b["norm"]),
                                       stream_ptr()), "dtt_clip_adamw_ex")
         return b["norm"] if mx > 0 else loss
 

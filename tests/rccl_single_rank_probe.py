@@ -67,5 +67,22 @@ print("graph leg: losses", l1, l2, "collectives per step", (len(calls) - n_warm)
 assert len(calls) - n_warm == 2 * len(red2.buckets)
 assert l2 < l1 and all(torch.isfinite(p).all() for p in model.parameters())
 assert any(float((p.detach() - w).abs().max()) > 0 for p, w in zip(model.parameters(), w_before))
+# ---- third leg: the sharded step's collectives on RCCL (reduce_scatter_tensor AVG, all_reduce, all_gather_into_tensor)
+torch.manual_seed(1)
+m2 = dtt_amd.DTTNetModel(g=8, n_sources=2, n_layers=3, n_idp_layers=1, n_fft=64, hop_length=16, n_heads=2, precision="fp32").cuda()
+m3 = dtt_amd.DTTNetModel(g=8, n_sources=2, n_layers=3, n_idp_layers=1, n_fft=64, hop_length=16, n_heads=2, precision="fp32").cuda()
+m3.load_state_dict(m2.state_dict())
+sh = ddist.ShardedClipAdamW(m2, lr=1e-3, weight_decay=1e-5, max_norm=0.5, force_collectives=True)
+rep = dtt_amd.ClipAdamW(m3.parameters(), lr=1e-3, weight_decay=1e-5, max_norm=0.5)
+for mm, oo in ((m2, sh), (m3, rep)):
+    spec, phase = dtt_amd.stft_mag_phase(x, 64, 16)
+    out = mm(spectrogram=spec, phase=phase, audio_length=800)
+    sum(p["audio"].pow(2).mean() for p in out["preds"]).backward()
+    nrm = float(oo.step())
+    print("norm", nrm, flush=True)
+torch.cuda.synchronize()
+worst = max(float((a - b).abs().max()) for a, b in zip(m2.parameters(), m3.parameters()))
+print("sharded (RCCL RS/AG, one rank) vs replicated step: worst parameter difference", worst, flush=True)
+assert worst < 2.5e-3
 dist.destroy_process_group()
 print("rccl single-rank probe ok")

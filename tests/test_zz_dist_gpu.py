@@ -20,16 +20,26 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _run_steps(rank, world, steps=2):
+def _run_steps(rank, world, steps=2, sharded=False):
     _setup_paths()
     import dtt_amd
-    from dtt_amd.dist import GradBucketReducer
+    from dtt_amd.dist import GradBucketReducer, ShardedClipAdamW
     from helpers import make_batch, to_dev
     dev = torch.device("cuda", 0)
     torch.manual_seed(5)
     model = dtt_amd.DTTNetModel(**KW).to(dev)
-    red = GradBucketReducer(model, bucket_bytes=64 << 10)     # several buckets
-    opt = dtt_amd.ClipAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5, max_norm=0.5)
+    if sharded:
+        # reduce-scatter -> clip + AdamW on this rank's shard -> all-gather (ShardedClipAdamW); replicas start equal
+        opt = ShardedClipAdamW(model, lr=1e-3, weight_decay=1e-5, max_norm=0.5)
+
+        class _NoReducer:
+            buckets = [0, 0]
+            zero_grad = staticmethod(opt.zero_grad)
+            finish = staticmethod(lambda: None)
+        red = _NoReducer()
+    else:
+        red = GradBucketReducer(model, bucket_bytes=64 << 10)     # several buckets
+        opt = dtt_amd.ClipAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5, max_norm=0.5)
     crit = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())
     full = make_batch(4, 800, 64, 16, seed=23)
     per = 4 // world
@@ -48,13 +58,13 @@ def _run_steps(rank, world, steps=2):
         b.update(crit(**b))
         b["loss"].backward()
         red.finish()
-        if grads is None:
+        if grads is None and not sharded:
             grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
         norms.append(float(opt.step()))
-    return {k: v.detach().cpu() for k, v in model.state_dict().items()}, norms, len(red.buckets), grads
+    return {k: v.detach().cpu() for k, v in model.state_dict().items()}, norms, len(red.buckets), grads or {}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sharded=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if os.environ.get("DTT_DIST_TRACE"):                      # debugging aid: where does a stuck rank sit
@@ -63,7 +73,7 @@ def _worker(rank, world, port, q):
         faulthandler.dump_traceback_later(45, exit=True, file=f)
     try:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        sd, norms, nb, grads = _run_steps(rank, world)
+        sd, norms, nb, grads = _run_steps(rank, world, sharded=sharded)
         if rank == 0:
             q.put(({k: v.numpy() for k, v in sd.items()}, norms, nb, {k: v.numpy() for k, v in grads.items()}))
         dist.barrier()
@@ -102,6 +112,35 @@ def test_two_ranks_match_one_process_over_the_whole_batch():
     for k, v in ref.items():
         d = (torch.from_numpy(got[k]) - v).abs()
         assert float(d.max()) <= 2.5e-3, (k, float(d.max()))
+
+
+def test_sharded_optimizer_step_two_ranks_match_one_process():
+    """reduce-scatter -> sum-of-squares of the shard + all-reduce of one float -> clip + AdamW on the shard ->
+    all-gather (ShardedClipAdamW, two gloo ranks on the one GPU) against one process with the replicated ClipAdamW
+    over the whole batch: global norms and parameters after two steps."""
+    world, port = 2, 33000 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=110)
+    assert not isinstance(res, str), res
+    got, norms, _, _ = res
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, ref_norms, _, _ = _run_steps(0, 1)
+    for a, b, tol in zip(norms, ref_norms, (1e-4, 3e-3)):
+        assert abs(a - b) <= tol * abs(b), (norms, ref_norms)
+    for k, v in ref.items():
+        d = (torch.from_numpy(got[k]) - v).abs()
+        assert float(d.max()) <= 2.5e-3, (k, float(d.max()))      # lr-sized Adam noise, as in the test above
+    # and a single process through the sharded class (world 1: the shard is everything) follows the replicated step
+    one, one_norms, _, _ = _run_steps(0, 1, sharded=True)
+    assert abs(one_norms[0] - ref_norms[0]) <= 1e-5 * abs(ref_norms[0])
+    for k, v in ref.items():
+        assert float((one[k] - v).abs().max()) <= 2.5e-3, k
 
 
 def test_reducer_async_path_over_rccl_one_rank():

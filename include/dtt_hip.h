@@ -164,6 +164,23 @@ int dtt_lstm_cluster_bwd(const void* dy, const void* gates_blk, const float* cst
                          float* dcbuf, float* dbias, unsigned* sync, int N, int L, int heads, int H, int dtype,
                          void* stream);
 
+/* Register-stationary form of the same recurrence (nn.LSTM forward / backward, latent.py:87-92) for bf16 at
+ * H = 512 and H = 256: W_hh lives in the VGPR/AGPR file of a cluster of 8 (H = 512) or 2 (H = 256) CUs for the
+ * whole launch (one wave per SIMD, 256 registers of MFMA operand fragments per lane), the h / dG tile of the
+ * previous step is fetched once per CU into LDS, and a cluster walks its 32-sequence tiles round-robin with one
+ * hand-off counter per tile.  Arguments as for dtt_lstm_cluster_fwd / _bwd, except the layout of the saved
+ * activations (private to the pair, same sizes): gates_blk [2][NT][L][H/4][32][4 gates][4 units] (bf16),
+ * cst_blk [2][NT][L][H/4][32][4] fp32; dcbuf [2][NT][H/4][32][4] fp32 scratch.
+ *   dtt_lstm_rs_supported: 0 when (N, H, dtype) is covered on this GPU, 1 otherwise.
+ *   sync: dtt_lstm_rs_sync_words(N, H) uint32 of scratch (zeroed by the call). */
+int dtt_lstm_rs_supported(int N, int H, int dtype);
+int dtt_lstm_rs_sync_words(int N, int H);
+int dtt_lstm_rs_fwd(const void* xg, const void* whh, void* y, void* gates_blk, float* cst_blk, unsigned* sync,
+                    int N, int L, int heads, int H, int dtype, void* stream);
+int dtt_lstm_rs_bwd(const void* dy, const void* gates_blk, const float* cst_blk, const void* whhT, void* dG,
+                    float* dcbuf, float* dbias, unsigned* sync, int N, int L, int heads, int H, int dtype,
+                    void* stream);
+
 /* ---------------------------------------------------------------------------
  * STFT / iSTFT glue (base_dataset.py:154-167; model_dttnet.py:77-85), the 1x1
  * input conv (encoder.py:26-27) and the fused out conv + mask + torch.polar

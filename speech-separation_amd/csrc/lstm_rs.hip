@@ -1,0 +1,736 @@
+// Register-stationary bidirectional LSTM recurrence (forward and backward through time) for the Improved Dual-Path
+// modules at the latent widths of the audio-visual and audio-only models (H = 512 / 256; reference:
+// src/model/DTTNet/modules/latent.py:87-92, nn.LSTM(C', 2C', bidirectional); gate order i, f, g, o).
+//
+// Why a third form.  lstm.hip re-streams W_hh from L2 every step (bound by the 64 B/clk vector-memory path of a CU);
+// lstm_cluster.hip keeps a 32-unit slice of W_hh in LDS, which at H = 512 takes 16 CUs per direction and sequence
+// group: every h row is re-read by 16 CUs, each wave fetches its own 32 KB tile of freshly published bytes, and a
+// step costs 12-34 us for 2-4 us of MFMA work.  The register file of a CU is 512 KB, three times its LDS: here the
+// recurrent weights live in VGPRs/AGPRs.  One workgroup = 4 waves = one wave per SIMD, 512 registers per lane, 256
+// of them hold the wave's share of W_hh as ready-made MFMA operand fragments for the whole launch (64 KB per wave,
+// 256 KB per CU): a cluster is 8 CUs at H = 512 and 2 at H = 256.
+//   * The GEMM is computed transposed, G^T = W . h^T: the weights are the A operand (32 gate rows x 16 k per
+//     fragment), the 32 sequences of a tile are the columns.  A 32-row weight tile is 8 hidden units x 4 gates, row
+//     8 * gate + unit: in the 32x32 accumulator layout a lane then holds, for ONE sequence, all four gates of 4
+//     units -- the cell update needs no cross-lane traffic.
+//   * The h tile of the previous step (32 sequences x H) is fetched ONCE per CU (every lane one 16-byte piece per
+//     wave-instruction, all of them in flight together) into LDS, from where the 4 waves read their B fragments;
+//     LDS holds nothing else, so its bandwidth is the fragments' alone (1 read per MT MFMAs).
+//   * A cluster walks its tiles round-robin inside a step, with one counter per tile: while the h of tile j is on
+//     its way through the fabric the CUs compute tile j + 1 (the loads of the next tile are issued ahead of the
+//     MFMAs of the current one).  A cluster with one tile (the frequency axis) is bound by the hand-off latency.
+// Hand-off (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table; hipMalloc memory, one workgroup per CU):
+//   producer: 16-byte sc1 (write-through) stores of its h slice -> every wave `s_waitcnt vmcnt(0)` -> workgroup
+//             barrier -> ONE lane adds 1 to the tile's counter (agent-scope atomic);
+//   consumer: every wave polls the counter itself (sc1 load, one lane) and only then issues its sc1 buffer loads of
+//             the handed-off bytes -- all loads of those bytes are such loads.
+// Every spin is bounded: on a timeout the kernel raises the status word and runs to completion.
+//
+// Saved activations (private to this pair of kernels), granule = (4 hidden units, one sequence):
+//   gates [2][NT][L][H/4][32 seq][4 gates][4 units] (bf16, 32 B per granule),  cst [2][NT][L][H/4][32 seq][4] (fp32).
+#include <algorithm>
+#include "common.h"
+#include "../../include/dtt_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+__device__ __forceinline__ float sigm_r(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float tanh_r(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+
+// MFMA with the A operand (the resident weights) read straight from an AGPR: the accumulator half of the register
+// file is the weight store, the architectural VGPRs are the working set.  hipcc pads nothing inside an asm
+// statement: `s_nop 1` covers a VALU / v_accvgpr_write producer of an operand; the accumulate chain itself needs no
+// states (D -> next MFMA's whole C), its readers are fenced by mfma_drain.
+__device__ __forceinline__ void mfma_wa(f32x16_t& acc, const s16x8_t& wa, const s16x8_t& b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wa), "v"(b));
+}
+template <int MT> __device__ __forceinline__ void mfma_drain(f32x16_t (&acc)[MT]) {
+    if constexpr (MT == 1) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]));
+    if constexpr (MT == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+    if constexpr (MT == 4) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+}
+
+// Diagnostic build only (-DRS_STAMP=<block>): shader-clock stamps of one wave's phases, read back with
+// dtt_lstm_rs_read_stamps; nothing is computed from them and the product build contains none of it.
+#ifdef RS_STAMP
+__device__ unsigned long long rs_stamps[128 * 16];
+#define STAMP(i) do { if (blockIdx.x == RS_STAMP && tid == 0 && q >= Q - 128) rs_stamps[(q - (Q - 128)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+constexpr unsigned SYNC_STRIDE = 64;          // uints between counters (256 B)
+constexpr unsigned SPIN_LIMIT = 1u << 19;     // bounded poll
+constexpr unsigned OOB = 0xfffffff0u;         // buffer offset beyond num_records: loads return 0, stores are dropped
+
+__device__ __forceinline__ float lo_bf(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// blocks b and b + 8 share an XCD (observed dispatch order; speed only): a cluster's G workgroups get ids of one
+// residue class when the clusters divide evenly over the 8 XCDs
+__device__ __forceinline__ void rs_role(int b, int G, int S, int& dir, int& sg, int& cg) {
+    const int P = 2 * S;
+    int q;
+    if (P % 8 == 0) {
+        const int x = b & 7, i = b >> 3;
+        q = x * (P >> 3) + i / G;
+        cg = i % G;
+    } else {
+        q = b / G;
+        cg = b % G;
+    }
+    dir = q / S;
+    sg = q - dir * S;
+}
+
+// every wave polls for itself (lane 0), the rest of the wave reconverges behind it
+__device__ __forceinline__ void rs_wait(unsigned* cnt, unsigned target, unsigned* status, bool& dead) {
+    if ((threadIdx.x & 63) == 0 && !dead) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) {
+                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+                break;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+struct LstmRF {
+    const void* xg;      // [rows][2][4H] bf16: input projection + biases
+    const void* whh;     // [2][4H][H] bf16, PyTorch layout
+    void* y;             // [rows][2H] bf16: output and the medium of the h exchange
+    void* gates;         // granules, may be NULL (inference)
+    float* cst;          // granules, required
+    unsigned* sync;      // one status word, then [2*S][TMAX] counters, all SYNC_STRIDE apart; zeroed by the entry point
+    int N, L, hshift, S, NT, TMAX;   // heads = 1 << hshift
+};
+
+// MT: 32-row weight tiles per wave (8 hidden units each); KS = H / 16 k-steps.  MT * KS = 64: 256 registers of weights.
+// DEEP: every cluster of the launch has >= 3 tiles (software pipeline over items), else the serial per-item form.
+template <int MT, int KS, bool DEEP>
+__global__ __launch_bounds__(256, 1) void lstm_rs_fwd_kernel(LstmRF p) {
+    constexpr int H = KS * 16, U = 32 * MT, G = H / U, G4 = 4 * H, LDH = H + 8, LDST = U + 8;
+    constexpr int CPRH = H / 8;                   // 16-byte pieces per h row
+    constexpr int NLD = 32 * CPRH / 256;          // pieces of a 32 x H tile per lane
+    constexpr int CPRU = U / 8;                   // pieces per published row segment
+    constexpr int NST = 32 * CPRU / 256;          // published pieces per lane
+    static_assert(NST >= 1 && MT * KS == 64, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* hbuf = reinterpret_cast<bf16*>(smem);                   // [2][32][LDH] h_{t-1} of the current / next tile
+    bf16* hst = hbuf + 2 * 32 * LDH;                                  // [32][LDST]  this CU's slice of h_t on its way out
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    int cg, sg, dir;
+    rs_role(blockIdx.x, G, p.S, dir, sg, cg);
+    const int u0 = cg * U, uw = u0 + wave * 8 * MT;                // first unit of the CU / of the wave
+    const int tile0 = (int)((long long)sg * p.NT / p.S), ntile = (int)((long long)(sg + 1) * p.NT / p.S) - tile0;
+    unsigned* cnt0 = p.sync + (size_t)((dir * p.S + sg) * p.TMAX + 1) * SYNC_STRIDE;
+    unsigned* status = p.sync;
+    const size_t rows = (size_t)p.N * p.L;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(rows * 2 * H * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xg), 0, (int)std::min<size_t>(rows * 2 * G4 * 2, 0xffffffe0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.whh), 0, 2 * G4 * H * 2, 0x00020000);
+    if (ntile <= 0) return;                                        // (the host never launches empty clusters)
+
+    // ---- resident weights: row (8 * gate + unit) of tile mt <- W_hh[gate * H + uw + 8 mt + unit][:], as A fragments
+    s16x8_t w[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const unsigned rowW = (unsigned)(dir * G4 + (lr >> 3) * H + uw + mt * 8 + (lr & 7));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            w[mt][ks] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rw, (rowW * H + ks * 16 + lh * 8) * 2, 0, 0));
+    }
+
+    bool dead = false;
+    u32x4_t hq[NLD];                                               // this lane's pieces of an h tile in flight
+    u32x2_t xq[MT][4];                                             // input projection of the lane's 4 units, per gate
+    float4 cq[MT];                                                 // c_{t-1} from memory (several tiles per cluster)
+    float4 creg[MT];                                               // c_{t-1} in registers (one tile per cluster)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) creg[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto row_base = [&](int n, int t) -> unsigned {               // row of sequence n at step t in xg / y
+        return (unsigned)(((((n >> p.hshift) * p.L + t) << p.hshift)) + (n & ((1 << p.hshift) - 1)));
+    };
+    auto issue_x = [&](int s, int tl) {
+        const int t = dir ? p.L - 1 - s : s, tprev = dir ? t + 1 : t - 1;
+        const int gt = tile0 + tl, n = gt * 32 + lr;
+        const bool ok = n < p.N;
+        const unsigned bx = ok ? ((row_base(n, t) * 2u + dir) * (unsigned)G4 + uw + 4 * lh) * 2u : OOB;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                xq[mt][g] = __builtin_amdgcn_raw_buffer_load_b64(rx, ok ? bx + (unsigned)(g * H + mt * 8) * 2u : OOB, 0, 0);
+        if ((DEEP || ntile > 1) && s > 0) {
+            const size_t slabp = ((size_t)dir * p.NT + gt) * p.L + tprev;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                cq[mt] = *reinterpret_cast<const float4*>(p.cst + ((slabp * (H / 4) + (uw + mt * 8) / 4 + lh) * 32 + lr) * 4);
+        }
+    };
+    auto issue_h = [&](int s, int tl) {                            // s > 0, after the tile's counter has matched
+        const int t = dir ? p.L - 1 - s : s, tprev = dir ? t + 1 : t - 1;
+        const int gt = tile0 + tl;
+#pragma unroll
+        for (int c = 0; c < NLD; ++c) {
+            const int idx = tid + 256 * c, row = idx / CPRH, part = idx - row * CPRH, n = gt * 32 + row;
+            const unsigned off = n < p.N ? ((row_base(n, tprev) * 2u + dir) * (unsigned)H + part * 8) * 2u : OOB;
+            hq[c] = __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 16);
+        }
+    };
+    auto commit_h = [&](bf16* dst) {
+#pragma unroll
+        for (int c = 0; c < NLD; ++c) {
+            const int idx = tid + 256 * c, row = idx / CPRH, part = idx - row * CPRH;
+            *reinterpret_cast<u32x4_t*>(dst + row * LDH + part * 8) = hq[c];
+        }
+    };
+    auto signal = [&](int tlx) {                                   // behind the drain of every wave's h stores
+        __syncthreads();                                           // B3
+        if (tid == 0) __hip_atomic_fetch_add(cnt0 + (size_t)tlx * SYNC_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    // Work items q = (step s, tile tl), tiles round-robin inside a step.  With >= 3 tiles per cluster the loop is a
+    // software pipeline over items (`deep`): the h tile of item q + 2 is requested while item q is being finished
+    // (its counter was read speculatively one phase earlier, so the poll costs no round trip and drains nothing),
+    // lands in registers during item q + 1 and is moved to the other LDS buffer there; the drain of item q's h
+    // stores and its signal wait until the MFMAs of item q + 1 have been issued.
+    const int Q = p.L * ntile;
+    constexpr bool deep = DEEP;
+    int s = 0, tl = 0;
+    int pend_tl = -1;                                              // deep: tile whose signal is still owed
+    unsigned pv = 0;
+    issue_x(0, 0);
+    if constexpr (DEEP) __builtin_amdgcn_s_waitcnt(0x0F70);       // nothing is in flight at the loop's entry either
+    for (int q = 0; q < Q; ++q) {
+        const int t = dir ? p.L - 1 - s : s;
+        const int gt = tile0 + tl;
+        int s1 = s, tl1 = tl + 1;
+        if (tl1 == ntile) { tl1 = 0; ++s1; }
+        int s2 = s1, tl2 = tl1 + 1;
+        if (tl2 == ntile) { tl2 = 0; ++s2; }
+        STAMP(0);
+        bf16* hcur = hbuf + (q & 1) * (32 * LDH);
+        bf16* hnext = hbuf + ((q + 1) & 1) * (32 * LDH);
+        if (!DEEP && s > 0) {
+            rs_wait(cnt0 + (size_t)tl * SYNC_STRIDE, (unsigned)(G * s), status, dead);
+            issue_h(s, tl);
+            commit_h(hcur);
+        }
+        __syncthreads();                                           // B1: the tile is in LDS (and hst is free again)
+        STAMP(1);
+        // ---- accumulators <- input projection; then the registers of xq / cq are free for the next item
+        f32x16_t acc[MT];
+        float4 cprev[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[mt][g * 4 + 0] = lo_bf(xq[mt][g][0]); acc[mt][g * 4 + 1] = hi_bf(xq[mt][g][0]);
+                acc[mt][g * 4 + 2] = lo_bf(xq[mt][g][1]); acc[mt][g * 4 + 3] = hi_bf(xq[mt][g][1]);
+            }
+            cprev[mt] = (DEEP || ntile > 1) ? (s > 0 ? cq[mt] : make_float4(0.f, 0.f, 0.f, 0.f)) : creg[mt];
+        }
+        const bool ahead2 = DEEP && q + 2 < Q && s2 > 0;           // item q + 2 needs an h tile
+        asm volatile("" ::: "memory");
+        if (ahead2) pv = __hip_atomic_load(cnt0 + (size_t)tl2 * SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (q + 1 < Q) issue_x(s1, tl1);
+        asm volatile("" ::: "memory");
+        STAMP(2);
+        // ---- recurrent term: B fragments of h_{t-1} from LDS, A fragments are the resident weights
+        if (s > 0) {
+            constexpr int BD = 4;                                  // B fragments in flight (one wave per SIMD: keep LDS reads ahead)
+            const bf16* hb = hcur + lr * LDH + lh * 8;
+            s16x8_t bq[BD];
+#pragma unroll
+            for (int d = 0; d < BD; ++d) bq[d] = *reinterpret_cast<const s16x8_t*>(hb + d * 16);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8_t b = bq[ks % BD];
+                if (ks + BD < KS) bq[ks % BD] = *reinterpret_cast<const s16x8_t*>(hb + (ks + BD) * 16);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mfma_wa(acc[mt], w[mt][ks], b);
+            }
+            mfma_drain(acc);
+        }
+        STAMP(3);
+        if constexpr (DEEP) {
+            // ONE point per item where the wave waits for vector memory (a wait the compiler sees: it adds none of its
+            // own afterwards): by now, one MFMA phase after the last issue, the previous item's stores have drained,
+            // the h tile requested an item ago and this phase's loads have landed
+            __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+            asm volatile("" ::: "memory");
+            STAMP(4);
+            if (pend_tl >= 0) { signal(pend_tl); pend_tl = -1; }
+            STAMP(5);
+            if (q + 1 < Q && s1 > 0) commit_h(hnext);              // requested one item ago
+            STAMP(6);
+            if (ahead2) {
+                if (pv < (unsigned)(G * s2)) rs_wait(cnt0 + (size_t)tl2 * SYNC_STRIDE, (unsigned)(G * s2), status, dead);
+                issue_h(s2, tl2);
+            }
+            STAMP(7);
+        }
+        // ---- gates and state update of the lane's 4 units per tile (accumulator r = 4 * gate + unit)
+        const size_t slab = ((size_t)dir * p.NT + gt) * p.L + t;
+        u32x4_t gpk[MT][2];
+        float4 cnew[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float gi[4], gf[4], gg[4], go[4], hv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                gi[u] = sigm_r(acc[mt][u]); gf[u] = sigm_r(acc[mt][4 + u]);
+                gg[u] = tanh_r(acc[mt][8 + u]); go[u] = sigm_r(acc[mt][12 + u]);
+                const float c = gf[u] * (&cprev[mt].x)[u] + gi[u] * gg[u];
+                (&cnew[mt].x)[u] = c;
+                hv[u] = go[u] * tanh_r(c);
+            }
+            creg[mt] = cnew[mt];
+            u32x2_t hp;
+            hp[0] = pack_bf16x2(hv[0], hv[1]); hp[1] = pack_bf16x2(hv[2], hv[3]);
+            *reinterpret_cast<u32x2_t*>(hst + lr * LDST + wave * 8 * MT + mt * 8 + 4 * lh) = hp;
+            gpk[mt][0][0] = pack_bf16x2(gi[0], gi[1]); gpk[mt][0][1] = pack_bf16x2(gi[2], gi[3]);
+            gpk[mt][0][2] = pack_bf16x2(gf[0], gf[1]); gpk[mt][0][3] = pack_bf16x2(gf[2], gf[3]);
+            gpk[mt][1][0] = pack_bf16x2(gg[0], gg[1]); gpk[mt][1][1] = pack_bf16x2(gg[2], gg[3]);
+            gpk[mt][1][2] = pack_bf16x2(go[0], go[1]); gpk[mt][1][3] = pack_bf16x2(go[2], go[3]);
+        }
+        STAMP(8);
+        __syncthreads();                                           // B2: the CU's slice of h_t is staged
+        STAMP(9);
+        // ---- h_t goes out FIRST (what the other CUs of the cluster wait for), the saved activations behind it
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < NST; ++c) {
+            const int idx = tid + 256 * c, row = idx / CPRU, part = idx - row * CPRU, n = gt * 32 + row;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(hst + row * LDST + part * 8);
+            const unsigned off = n < p.N ? ((row_base(n, t) * 2u + dir) * (unsigned)H + u0 + part * 8) * 2u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, off, 0, 16);
+        }
+        asm volatile("" ::: "memory");
+        if (s + 1 < p.L) {
+            if constexpr (DEEP) pend_tl = tl;
+            else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); signal(tl); }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const size_t gr = (slab * (H / 4) + (uw + mt * 8) / 4 + lh) * 32 + lr;
+            *reinterpret_cast<float4*>(p.cst + gr * 4) = cnew[mt];
+            if (p.gates) {
+                u32x4_t* gd = reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16*>(p.gates) + gr * 16);
+                gd[0] = gpk[mt][0];
+                gd[1] = gpk[mt][1];
+            }
+        }
+        asm volatile("" ::: "memory");
+        STAMP(10);
+        s = s1; tl = tl1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward through time.  Per step  dh_t[n, u] = dy_t[n, u] + sum_k dG_{t+1}[n, k] W_hh[k][u]  (k over the 4H gate
+// columns), then the gate gradients of the units, published as the CU's 4U columns of the row-major dG buffer,
+// which is the exchange medium (the weight-gradient GEMMs read it afterwards anyway).
+// Same clusters as the forward kernel (a CU owns U = H / G hidden units), but here the four waves of a CU split K:
+// wave w keeps W_hh[w * H .. (w + 1) * H, the CU's units] (a quarter of the gate columns, all U units: 64 KB of
+// 16x16x32 A fragments in its AGPRs) and needs only ITS quarter of a dG row.  So the B fragments go straight from
+// the exchange buffer into registers (sc1 loads in fragment order, a rolling window of them in flight; each feeds
+// U / 16 MFMAs) -- the tile never passes through LDS -- and LDS carries only the partial sums of the four waves
+// (32 x U fp32 per wave) and the outgoing dG slice.  Wave w finishes the units [w * U / 4, (w + 1) * U / 4).
+struct LstmRB {
+    const void* dy;      // [rows][2H] bf16
+    const void* gates;   // granules (bf16)
+    const float* cst;    // granules
+    const void* whhT;    // [2][H][4H] bf16: W_hh^T per direction
+    void* dG;            // [rows][2][4H] bf16: output and exchange medium
+    float* dcbuf;        // [2][NT][H/4][32][4] fp32: running dc of clusters with several tiles
+    float* dbias;        // [2][4H] fp32, zeroed by the caller (may be NULL)
+    unsigned* sync;
+    int N, L, hshift, S, NT, TMAX;
+};
+
+__device__ __forceinline__ void mfma16_wa(f32x4_t& acc, const s16x8_t& wa, const s16x8_t& b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wa), "v"(b));
+}
+
+// MTB: 16-unit weight tiles per CU (U = 16 MTB); KSB = H / 32 k-steps of 32 per wave.  MTB * KSB = 64 fills the
+// AGPRs (H = 512: U = 64); H = 256 runs with MTB * KSB = 32 (U = 64, 4 CUs per cluster): the 128-unit form needs
+// twice the per-lane epilogue state and spills.
+template <int MTB, int KSB, bool DEEP>
+__global__ __launch_bounds__(256, 1) void lstm_rs_bwd_kernel(LstmRB p) {
+    constexpr int H = KSB * 32, U = 16 * MTB, G = H / U, G4 = 4 * H, KQ = H;     // KQ: gate columns per wave
+    constexpr int MW = MTB / 4;                   // tiles a wave finishes
+    constexpr int NLB = 2 * KSB;                  // B fragments per item: (k-step, 16-sequence half)
+    constexpr int W = NLB >= 32 ? 16 : 8;         // fragments in flight
+    constexpr int LDG = 4 * U + 8;                // staging row (elements): 4 gates x U units
+    constexpr int CPRG = 4 * U / 8;               // 16-byte pieces per staged row
+    constexpr int NST = 32 * CPRG / 256;          // published pieces per lane
+    static_assert(MTB * KSB <= 64 && MTB == 4 && NLB % W == 0 && MW >= 1, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);                              // [4 waves][MTB][2][64]
+    bf16* dgs = reinterpret_cast<bf16*>(smem + (size_t)4 * MTB * 2 * 64 * 16);    // [32][LDG]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sq = lane & 15, rg = lane >> 4;
+    int cg, sg, dir;
+    rs_role(blockIdx.x, G, p.S, dir, sg, cg);
+    const int u0 = cg * U;
+    const int tile0 = (int)((long long)sg * p.NT / p.S), ntile = (int)((long long)(sg + 1) * p.NT / p.S) - tile0;
+    unsigned* cnt0 = p.sync + (size_t)((dir * p.S + sg) * p.TMAX + 1) * SYNC_STRIDE;
+    unsigned* status = p.sync;
+    const size_t rows = (size_t)p.N * p.L;
+    const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc(p.dG, 0, (int)std::min<size_t>(rows * 2 * G4 * 2, 0xffffffe0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)(rows * 2 * H * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.whhT), 0, 2 * G4 * H * 2, 0x00020000);
+    if (ntile <= 0) return;
+
+    // ---- resident weights: A fragment (tile mt, k-step ks) <- W_hh^T[u0 + 16 mt + (lane & 15)][wave * KQ + 32 ks + 8 (lane >> 4) ..]
+    s16x8_t w[MTB][KSB];
+#pragma unroll
+    for (int mt = 0; mt < MTB; ++mt) {
+        const unsigned rowW = (unsigned)(dir * H + u0 + mt * 16 + sq);
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks)
+            w[mt][ks] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rw, (rowW * G4 + wave * KQ + ks * 32 + rg * 8) * 2, 0, 0));
+    }
+
+    bool dead = false;
+    auto row_base = [&](int n, int t) -> unsigned {
+        return (unsigned)(((((n >> p.hshift) * p.L + t) << p.hshift)) + (n & ((1 << p.hshift) - 1)));
+    };
+    // byte offsets of this lane's B fragments (the two 16-sequence halves) of the dG tile published at step `tn`
+    auto frag_base = [&](int gt, int tn, bool valid, unsigned (&fb)[2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = gt * 32 + nt * 16 + sq;
+            fb[nt] = (valid && n < p.N) ? ((row_base(n, tn) * 2u + dir) * (unsigned)G4 + wave * KQ + rg * 8) * 2u : OOB;
+        }
+    };
+    auto ld_frag = [&](const unsigned (&fb)[2], int j) -> u32x4_t {                // j = 2 * ks + nt
+        const unsigned b = fb[j & 1];
+        return __builtin_amdgcn_raw_buffer_load_b128(rg_, b == OOB ? OOB : b + (unsigned)((j >> 1) * 64), 0, 16);
+    };
+    auto signal = [&](int tlx) {
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt0 + (size_t)tlx * SYNC_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    // side data of an item (does not depend on the exchange): saved gates, c_t, c_{t-1}, dy, running dc, per granule
+    // (tile mi of the wave, half nt): granule (4 units ug, sequence nt * 16 + sq)
+    u32x4_t gq[MW][2][2];
+    float4 ctq[MW][2], cpq[MW][2], dcq[MW][2];
+    u32x2_t dyq[MW][2];
+    float4 dcreg[MW][2];                                           // running dc, clusters with one tile
+    float dbs[MW][16];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) dcreg[mi][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dbs[mi][r] = 0.f;
+    }
+    auto issue_side = [&](int s, int tl) {
+        const int t = dir ? p.L - 1 - s : s, tprev = dir ? t + 1 : t - 1;
+        const int gt = tile0 + tl;
+        const size_t slab = ((size_t)dir * p.NT + gt) * p.L + t;
+        const size_t slabp = ((size_t)dir * p.NT + gt) * p.L + (s > 0 ? tprev : t);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            const int ug = (u0 + (wave * MW + mi) * 16) / 4 + rg;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int sl = nt * 16 + sq, n = gt * 32 + sl;
+                const size_t gr = (slab * (H / 4) + ug) * 32 + sl, grp = (slabp * (H / 4) + ug) * 32 + sl;
+                const u32x4_t* gs = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16*>(p.gates) + gr * 16);
+                gq[mi][nt][0] = gs[0];
+                gq[mi][nt][1] = gs[1];
+                ctq[mi][nt] = *reinterpret_cast<const float4*>(p.cst + gr * 4);
+                cpq[mi][nt] = *reinterpret_cast<const float4*>(p.cst + grp * 4);
+                dyq[mi][nt] = __builtin_amdgcn_raw_buffer_load_b64(rdy, n < p.N ? ((row_base(n, t) * 2u + dir) * (unsigned)H + ug * 4) * 2u : OOB, 0, 0);
+                if (DEEP || ntile > 1)
+                    dcq[mi][nt] = *reinterpret_cast<const float4*>(p.dcbuf + ((((size_t)dir * p.NT + gt) * (H / 4) + ug) * 32 + sl) * 4);
+            }
+        }
+    };
+
+    const int Q = p.L * ntile;
+    int s = p.L - 1, tl = 0;                                       // items walk the steps downwards
+    int pend_tl = -1;
+    unsigned pv = 0;
+    unsigned fb[2] = {OOB, OOB}, fbn[2] = {OOB, OOB};
+    u32x4_t bq[W];
+    // the window of the first item: nothing to fetch (its dh is dy alone), keep the registers defined
+#pragma unroll
+    for (int d = 0; d < W; ++d) bq[d] = u32x4_t{0u, 0u, 0u, 0u};
+    for (int q = 0; q < Q; ++q) {
+        const int t = dir ? p.L - 1 - s : s;
+        const int tnext = dir ? t - 1 : t + 1;                    // the step processed one iteration of s earlier
+        const bool first = s == p.L - 1;
+        const int gt = tile0 + tl;
+        int s1 = s, tl1 = tl + 1;
+        if (tl1 == ntile) { tl1 = 0; --s1; }
+        const bool has_next = q + 1 < Q;
+        const bool next_first = s1 == p.L - 1;
+        STAMP(0);
+        issue_side(s, tl);
+        if constexpr (DEEP) {
+            // next item's counter, read ahead of its use (no round trip, no drain at the check)
+            pv = __hip_atomic_load(cnt0 + (size_t)tl1 * SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            frag_base(tile0 + tl1, dir ? (dir ? p.L - 1 - s1 : s1) - 1 : (dir ? p.L - 1 - s1 : s1) + 1, has_next && !next_first, fbn);
+        } else {
+            if (!first) {
+                rs_wait(cnt0 + (size_t)tl * SYNC_STRIDE, (unsigned)(G * (p.L - 1 - s)), status, dead);
+                frag_base(gt, tnext, true, fb);
+#pragma unroll
+                for (int d = 0; d < W; ++d) bq[d] = ld_frag(fb, d);
+            }
+            fbn[0] = OOB; fbn[1] = OOB;
+        }
+        STAMP(1);
+        // ---- partial dh over this wave's quarter of the gate columns
+        f32x4_t acc[MTB][2];
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (!first || DEEP) {
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) {
+                const s16x8_t b = __builtin_bit_cast(s16x8_t, bq[j % W]);
+                if constexpr (DEEP) {
+                    if (j == NLB - W) {                            // the window is about to wrap into the next item
+                        if (has_next && !next_first && pv < (unsigned)(G * (p.L - 1 - s1)))
+                            rs_wait(cnt0 + (size_t)tl1 * SYNC_STRIDE, (unsigned)(G * (p.L - 1 - s1)), status, dead);
+                    }
+                    if (j == W && pend_tl >= 0) {                  // the previous item's stores have had W fragments' time
+                        // counted: younger than its dG stores are its dc stores, this item's side loads, the counter
+                        // read and the W refills issued so far (every one of them issued unconditionally)
+                        constexpr int NY = MW * 2 + MW * 2 * 6 + 1 + W;
+                        __builtin_amdgcn_s_waitcnt((NY & 15) | ((NY >> 4) << 14) | 0x0F70);
+                        signal(pend_tl);
+                        pend_tl = -1;
+                    }
+                }
+                if (j + W < NLB) bq[j % W] = ld_frag(fb, j + W);
+                else if (DEEP) bq[j % W] = ld_frag(fbn, j + W - NLB);
+#pragma unroll
+                for (int mt = 0; mt < MTB; ++mt) mfma16_wa(acc[mt][j & 1], w[mt][j >> 1], b);
+            }
+        }
+        if constexpr (DEEP) { fb[0] = fbn[0]; fb[1] = fbn[1]; }
+        STAMP(2);
+        // ---- sum the four waves' partials: every wave leaves its own in LDS, wave w collects its MW tiles
+        {
+            // fence the accumulators behind the MFMA chain
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                if (mt / MW != wave) red[((wave * MTB + mt) * 2 + nt) * 64 + lane] = acc[mt][nt];
+        __syncthreads();                                           // R1
+        STAMP(3);
+        f32x4_t dh[MW][2];
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4_t v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mt = 0; mt < MTB; ++mt) if (mt / MW == wave && mt % MW == mi) v = acc[mt][nt];   // (wave-uniform select)
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv)
+                    if (wv != wave) v += red[((wv * MTB + wave * MW + mi) * 2 + nt) * 64 + lane];
+                dh[mi][nt] = v;
+            }
+        // ---- gate gradients of the wave's units
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            const int ul = (wave * MW + mi) * 16 + rg * 4;         // first of the lane's 4 units inside the CU's slice
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int sl = nt * 16 + sq;
+                const bool ok = gt * 32 + sl < p.N;
+                const unsigned* gw0 = reinterpret_cast<const unsigned*>(&gq[mi][nt][0]);
+                const unsigned* gw1 = reinterpret_cast<const unsigned*>(&gq[mi][nt][1]);
+                float4 dcn;
+                float dgv[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned wi = gw0[u >> 1], wf = gw0[2 + (u >> 1)], wg = gw1[u >> 1], wo = gw1[2 + (u >> 1)];
+                    const float gi = (u & 1) ? hi_bf(wi) : lo_bf(wi), gf = (u & 1) ? hi_bf(wf) : lo_bf(wf);
+                    const float gg = (u & 1) ? hi_bf(wg) : lo_bf(wg), go = (u & 1) ? hi_bf(wo) : lo_bf(wo);
+                    const unsigned wy = dyq[mi][nt][u >> 1];
+                    const float dyv = (u & 1) ? hi_bf(wy) : lo_bf(wy);
+                    const float cpv = s > 0 ? (&cpq[mi][nt].x)[u] : 0.f;
+                    const float dcp = first ? 0.f : ((DEEP || ntile > 1) ? (&dcq[mi][nt].x)[u] : (&dcreg[mi][nt].x)[u]);
+                    const float dhv = dyv + dh[mi][nt][u];
+                    const float tc = tanh_r((&ctq[mi][nt].x)[u]);
+                    const float dcv = dcp + dhv * go * (1.f - tc * tc);
+                    dgv[3][u] = ok ? dhv * tc * go * (1.f - go) : 0.f;
+                    dgv[0][u] = ok ? dcv * gg * gi * (1.f - gi) : 0.f;
+                    dgv[1][u] = ok ? dcv * cpv * gf * (1.f - gf) : 0.f;
+                    dgv[2][u] = ok ? dcv * gi * (1.f - gg * gg) : 0.f;
+                    (&dcn.x)[u] = dcv * gf;
+                }
+                dcreg[mi][nt] = dcn;
+                dcq[mi][nt] = dcn;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2_t pk;
+                    pk[0] = pack_bf16x2(dgv[g][0], dgv[g][1]); pk[1] = pack_bf16x2(dgv[g][2], dgv[g][3]);
+                    *reinterpret_cast<u32x2_t*>(dgs + sl * LDG + g * U + ul) = pk;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) dbs[mi][g * 4 + u] += dgv[g][u];
+                }
+            }
+        }
+        STAMP(4);
+        __syncthreads();                                           // R2: the CU's dG slice is staged
+        // ---- gate gradients go out FIRST (the other CUs wait for them): row-major 16-byte sc1 stores
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < NST; ++c) {
+            const int idx = tid + 256 * c, row = idx / CPRG, part = idx - row * CPRG, n = gt * 32 + row;
+            const int g = part / (U / 8), pu = part - g * (U / 8);
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(dgs + row * LDG + part * 8);
+            const unsigned off = n < p.N ? ((row_base(n, t) * 2u + dir) * (unsigned)G4 + g * H + u0 + pu * 8) * 2u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rg_, off, 0, 16);
+        }
+        asm volatile("" ::: "memory");
+        if (s > 0) {
+            if constexpr (DEEP) pend_tl = tl;
+            else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); signal(tl); }
+        }
+        if ((DEEP || ntile > 1) && s > 0) {
+#pragma unroll
+            for (int mi = 0; mi < MW; ++mi) {
+                const int ug = (u0 + (wave * MW + mi) * 16) / 4 + rg;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    *reinterpret_cast<float4*>(p.dcbuf + ((((size_t)dir * p.NT + gt) * (H / 4) + ug) * 32 + nt * 16 + sq) * 4) = dcq[mi][nt];
+            }
+        }
+        asm volatile("" ::: "memory");
+        STAMP(5);
+        s = s1; tl = tl1;
+    }
+    if (p.dbias) {
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = dbs[mi][r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (sq == 0) atomicAdd(p.dbias + (size_t)dir * G4 + (r >> 2) * H + u0 + (wave * MW + mi) * 16 + rg * 4 + (r & 3), v);
+            }
+    }
+}
+
+constexpr int RS_MAX_TILES = 64;              // counters per cluster the entry points accept
+int g_rs_cus = 0;
+int rs_num_cus() {
+    if (!g_rs_cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+        g_rs_cus = pr.multiProcessorCount;
+    }
+    return g_rs_cus;
+}
+
+// G CUs per cluster, S clusters per direction, TMAX tiles per cluster at most; false when (H, dtype, N) is not covered
+bool rs_geometry(int N, int H, int dtype, bool bwd, int& G, int& S, int& NT, int& TMAX) {
+    if (dtype != 1 || (H != 512 && H != 256) || N <= 0) return false;
+    const int ncu = rs_num_cus();
+    G = H == 512 ? 8 : (bwd ? 4 : 2);
+    if (ncu < 2 * G) return false;
+    NT = (N + 31) / 32;
+    S = std::min(NT, ncu / (2 * G));
+    TMAX = (NT + S - 1) / S;
+    return TMAX <= RS_MAX_TILES;
+}
+
+}  // namespace
+
+#ifdef RS_STAMP
+extern "C" int dtt_lstm_rs_read_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(rs_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
+extern "C" int dtt_lstm_rs_supported(int N, int H, int dtype) {
+    int G, S, NT, TMAX;
+    return rs_geometry(N, H, dtype, false, G, S, NT, TMAX) && rs_geometry(N, H, dtype, true, G, S, NT, TMAX) ? 0 : 1;
+}
+
+extern "C" int dtt_lstm_rs_sync_words(int N, int H) {
+    int G, S, NT, TMAX, words = 0;
+    for (int bwd = 0; bwd < 2; ++bwd) {                     // one size serves both calls
+        if (!rs_geometry(N, H, 1, bwd != 0, G, S, NT, TMAX)) return 0;
+        words = std::max(words, (2 * S * TMAX + 1) * (int)SYNC_STRIDE);
+    }
+    return words;
+}
+
+extern "C" int dtt_lstm_rs_fwd(const void* xg, const void* whh, void* y, void* gates_blk, float* cst_blk, unsigned* sync,
+                               int N, int L, int heads, int H, int dtype, void* stream) {
+    int G, S, NT, TMAX;
+    DTT_CHECK(rs_geometry(N, H, dtype, false, G, S, NT, TMAX), "dtt_lstm_rs_fwd: unsupported shape H=%d N=%d dtype=%d", H, N, dtype);
+    DTT_CHECK(L > 0 && heads > 0 && N % heads == 0 && xg && whh && y && cst_blk && sync, "dtt_lstm_rs_fwd: bad arguments");
+    int hshift = 0;
+    while ((1 << hshift) < heads) ++hshift;
+    DTT_CHECK((1 << hshift) == heads && heads <= 32, "dtt_lstm_rs_fwd: heads = %d is not a power of two <= 32", heads);
+    DTT_CHECK((int64_t)N * L * 2 * 4 * H * 2 < (1LL << 32) - 64, "dtt_lstm_rs_fwd: xg exceeds 32-bit byte offsets");
+    LstmRF p{xg, whh, y, gates_blk, cst_blk, sync, N, L, hshift, S, NT, TMAX};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DTT_CHECK(hipMemsetAsync(sync, 0, (size_t)dtt_lstm_rs_sync_words(N, H) * 4, st) == hipSuccess, "dtt_lstm_rs_fwd: memset failed");
+    const dim3 grid(2 * S * G), block(256);
+    const int U = H / G;
+    const size_t sm = ((size_t)2 * 32 * (H + 8) + (size_t)32 * (U + 8)) * 2;
+#define LAUNCH_RF(MTV, KSV, DP) do { auto k = lstm_rs_fwd_kernel<MTV, KSV, DP>; \
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
+    const bool deep = NT / S >= 3;                          // the smallest cluster has floor(NT / S) tiles
+    if (H == 512) { if (deep) LAUNCH_RF(2, 32, true); else LAUNCH_RF(2, 32, false); }
+    else { if (deep) LAUNCH_RF(4, 16, true); else LAUNCH_RF(4, 16, false); }
+#undef LAUNCH_RF
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_lstm_rs_bwd(const void* dy, const void* gates_blk, const float* cst_blk, const void* whhT, void* dG,
+                               float* dcbuf, float* dbias, unsigned* sync, int N, int L, int heads, int H, int dtype,
+                               void* stream) {
+    int G, S, NT, TMAX;
+    DTT_CHECK(rs_geometry(N, H, dtype, true, G, S, NT, TMAX), "dtt_lstm_rs_bwd: unsupported shape H=%d N=%d dtype=%d", H, N, dtype);
+    DTT_CHECK(L > 0 && heads > 0 && N % heads == 0 && dy && gates_blk && cst_blk && whhT && dG && dcbuf && sync,
+              "dtt_lstm_rs_bwd: bad arguments");
+    int hshift = 0;
+    while ((1 << hshift) < heads) ++hshift;
+    DTT_CHECK((1 << hshift) == heads && heads <= 32, "dtt_lstm_rs_bwd: heads = %d is not a power of two <= 32", heads);
+    DTT_CHECK((int64_t)N * L * 2 * 4 * H * 2 < (1LL << 32) - 64, "dtt_lstm_rs_bwd: dG exceeds 32-bit byte offsets");
+    LstmRB p{dy, gates_blk, cst_blk, whhT, dG, dcbuf, dbias, sync, N, L, hshift, S, NT, TMAX};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DTT_CHECK(hipMemsetAsync(sync, 0, (size_t)dtt_lstm_rs_sync_words(N, H) * 4, st) == hipSuccess, "dtt_lstm_rs_bwd: memset failed");
+    const dim3 grid(2 * S * G), block(256);
+    const int U = H / G, MTB = U / 16;
+    const size_t sm = (size_t)4 * MTB * 2 * 64 * 16 + (size_t)32 * (4 * U + 8) * 2;
+#define LAUNCH_RB(MTV, KSV, DP) do { auto k = lstm_rs_bwd_kernel<MTV, KSV, DP>; \
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
+    const bool deep = NT / S >= 3;
+    if (H == 512) { if (deep) LAUNCH_RB(4, 16, true); else LAUNCH_RB(4, 16, false); }
+    else { if (deep) LAUNCH_RB(4, 8, true); else LAUNCH_RB(4, 8, false); }
+#undef LAUNCH_RB
+    DTT_LAUNCH_CHECK();
+    return 0;
+}

@@ -437,8 +437,17 @@ def _cluster_geometry(N, H, d):
 
 
 def _lstm_mode():
-    """DTT_LSTM = auto | cluster | stream (A/B switch between the recurrent kernel families)."""
+    """DTT_LSTM = auto | rs | cluster | stream (A/B switch between the recurrent kernel families)."""
     return os.environ.get("DTT_LSTM", "auto")
+
+
+def _rs_ok(N, H, d, heads, mode):
+    """Register-stationary kernels (lstm_rs.hip): bf16, H = 512 (auto) or H in {256, 512} (DTT_LSTM=rs)."""
+    if mode not in ("auto", "rs") or heads & (heads - 1) or heads > 32:
+        return False
+    if mode == "auto" and H != 512:
+        return False
+    return lib().dtt_lstm_rs_supported(N, H, d) == 0
 
 
 class DualPathRNN(torch.autograd.Function):
@@ -474,9 +483,23 @@ class DualPathRNN(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         N = nslab * heads
         mode = _lstm_mode()
-        blocked = dt == torch.bfloat16 and H == 256 and Cp == 128 and mode != "cluster"
-        geom = None if (blocked or mode == "stream") else _cluster_geometry(N, H, d)
-        if geom is not None:
+        rs = _rs_ok(N, H, d, heads, mode)
+        blocked = dt == torch.bfloat16 and H == 256 and Cp == 128 and mode not in ("cluster", "rs")
+        geom = None if (rs or blocked or mode == "stream") else _cluster_geometry(N, H, d)
+        if rs:
+            # recurrent weights resident in the register file of a cluster of CUs (lstm_rs.hip): input projection
+            # by GEMM, h exchanged through y, activations saved as (4 units, 1 sequence) granules
+            xg = _empty((R, 8 * H), dt, dev)
+            gemm_raw(A=xn, B=wih, C=xg, bias=bsum, M=R, N=8 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=1, b_ns=Cp,
+                     c_ms=8 * H, c_ns=1, dtype=d, bias_mode=1)
+            NT = (N + 31) // 32
+            whh = torch.stack([w_hh, w_hh_r]).to(dt).contiguous()              # [2][4H][H]
+            gates = _empty((2, NT, L, 4 * H * 32), dt, dev) if need else None
+            cst = _empty((2, NT, L, H * 32), F32, dev)
+            sync = _empty((lib().dtt_lstm_rs_sync_words(N, H),), torch.int32, dev)
+            check(lib().dtt_lstm_rs_fwd(ptr(xg), ptr(whh), ptr(y), ptr(gates), ptr(cst), ptr(sync), N, L, heads, H,
+                                        d, stream_ptr()), "dtt_lstm_rs_fwd")
+        elif geom is not None:
             # weight-stationary recurrence over a cluster of CUs (lstm_cluster.hip): input projection by GEMM,
             # W_hh resident in LDS, h exchanged through y; activations saved in the blocked layout
             xg = _empty((R, 8 * H), dt, dev)
@@ -517,14 +540,14 @@ class DualPathRNN(torch.autograd.Function):
         gemm_raw(A=y, B=fcw, C=out, bias=fc_b, R=res, M=R, N=Cp, K=2 * H, a_ms=2 * H, a_ks=1, b_ks=1, b_ns=2 * H,
                  c_ms=Cp, c_ns=1, r_ms=Cp, r_ns=1, dtype=d, bias_mode=1)
         ctx.save_for_backward(x, gamma, xn, gstats, wih, w_hh, w_hh_r, y, gates, cst, fcw)
-        ctx.cfg = (heads, along_f, geo, gs, blocked, geom)
+        ctx.cfg = (heads, along_f, geo, gs, blocked, geom, rs)
         # along_f: memory order is [B,T,F,C]; the view below is the reference's merge_heads quirk
         return out.view(B, Fq, T, Cc)
 
     @staticmethod
     def backward(ctx, dout):
         x, gamma, xn, gstats, wih, w_hh, w_hh_r, y, gates, cst, fcw = ctx.saved_tensors
-        heads, along_f, geo, gs, blocked, geom = ctx.cfg
+        heads, along_f, geo, gs, blocked, geom, rs = ctx.cfg
         nslab, NI, L, Cc, Cp = geo[0], geo[1], geo[2], geo[3], geo[4]
         dt, dev, d = x.dtype, x.device, _dt(x)
         H = w_hh.shape[1]
@@ -544,7 +567,16 @@ class DualPathRNN(torch.autograd.Function):
         # recurrent backward
         dG = _empty((R, 2, 4 * H), dt, dev)
         dbias = None
-        if geom is not None:
+        if rs:
+            N = nslab * heads
+            NT = (N + 31) // 32
+            whhT = torch.stack([w_hh.t(), w_hh_r.t()]).to(dt).contiguous()     # [2][H][4H]
+            dcbuf = _empty((2, NT, H * 32), F32, dev)
+            dbias = _zeros_f32((2 * 4 * H,), dev)
+            sync = _empty((lib().dtt_lstm_rs_sync_words(N, H),), torch.int32, dev)
+            check(lib().dtt_lstm_rs_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(whhT), ptr(dG), ptr(dcbuf), ptr(dbias),
+                                        ptr(sync), N, L, heads, H, d, stream_ptr()), "dtt_lstm_rs_bwd")
+        elif geom is not None:
             N = nslab * heads
             NT = (N + 31) // 32
             whhT = torch.stack([w_hh.t(), w_hh_r.t()]).to(dt).contiguous()     # [2][H][4H]

@@ -337,6 +337,225 @@ __global__ __launch_bounds__(256, 1) void lstm_rs_fwd_kernel(LstmRF p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Forward, clusters with >= 4 tiles (the time axis): the same arithmetic as lstm_rs_fwd_kernel, organised so that
+// the one wave of a SIMD never sits in front of the vector-memory pipe with nothing to compute.  Phase stamps of
+// the kernel above showed 45 % of an item spent ISSUING loads and stores back to back (input projection, h tile,
+// saved activations: the pipe accepts them at the rate of the fabric) between the MFMA phases.  Here EVERY
+// vector-memory operation of an item except its h stores is issued from inside the MFMA loop, one or two per
+// k-step, and they belong to three different items:
+//   k-steps, first part:  h_{q+1} tile, fetched during the previous item, moves from registers to the other LDS buffer;
+//   then:                 input projection and c_{t-1} of item q + 1;
+//   then:                 (counter of item q + 2, read at the top of the item, is checked) h tile of item q + 2;
+//   last part:            saved activations (c, gates) of item q - 1.
+// All of them are issued unconditionally (disabled ones with an out-of-range buffer offset), so their number is a
+// compile-time constant and the two waits of an item are COUNTED: `vmcnt(NST)` at the top (everything but the h
+// stores just issued), `vmcnt(NDUR)` behind the MFMAs (the previous item's h stores; then its signal).
+template <int MT, int KS>
+__global__ __launch_bounds__(256, 1) void lstm_rs_fwd_deep_kernel(LstmRF p) {
+    constexpr int H = KS * 16, U = 32 * MT, G = H / U, G4 = 4 * H, LDH = H + 8, LDST = U + 8;
+    constexpr int CPRH = H / 8, NLD = 32 * CPRH / 256, CPRU = U / 8, NST = 32 * CPRU / 256;
+    constexpr int NX = 4 * MT, NC = MT, NPC = MT, NPG = 2 * MT;
+    constexpr int A_X = NLD, A_C = A_X + NX, A_H = A_C + NC, A_PC = A_H + NLD, A_PG = A_PC + NPC, NA = A_PG + NPG;
+    constexpr int NDUR = 1 + NX + NC + NLD + NPC + NPG;           // vector-memory operations between two items' h stores
+    static_assert(NST >= 1 && MT * KS == 64 && NDUR < 60, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* hbuf = reinterpret_cast<bf16*>(smem);                   // [2][32][LDH]
+    bf16* hst = hbuf + 2 * 32 * LDH;                              // [32][LDST]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    int cg, sg, dir;
+    rs_role(blockIdx.x, G, p.S, dir, sg, cg);
+    const int u0 = cg * U, uw = u0 + wave * 8 * MT;
+    const int tile0 = (int)((long long)sg * p.NT / p.S), ntile = (int)((long long)(sg + 1) * p.NT / p.S) - tile0;
+    unsigned* cnt0 = p.sync + (size_t)((dir * p.S + sg) * p.TMAX + 1) * SYNC_STRIDE;
+    unsigned* status = p.sync;
+    const size_t rows = (size_t)p.N * p.L, ngran = (size_t)2 * p.NT * p.L * (H / 4) * 32;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(rows * 2 * H * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xg), 0, (int)std::min<size_t>(rows * 2 * G4 * 2, 0xffffffe0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.whh), 0, 2 * G4 * H * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.cst, 0, (int)(ngran * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rgt = __builtin_amdgcn_make_buffer_rsrc(p.gates, 0, p.gates ? (int)(ngran * 32) : 0, 0x00020000);
+    if (ntile <= 0) return;
+
+    s16x8_t w[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const unsigned rowW = (unsigned)(dir * G4 + (lr >> 3) * H + uw + mt * 8 + (lr & 7));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            w[mt][ks] = __builtin_bit_cast(s16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rw, (rowW * H + ks * 16 + lh * 8) * 2, 0, 0));
+    }
+    // both LDS tile buffers start as zeros (the items of step 0 multiply them: h_{-1} = 0)
+    for (int i = tid; i < 2 * 32 * LDH / 8; i += 256) reinterpret_cast<u32x4_t*>(hbuf)[i] = u32x4_t{0u, 0u, 0u, 0u};
+
+    bool dead = false;
+    auto row_base = [&](int n, int t) -> unsigned {
+        return (unsigned)(((((n >> p.hshift) * p.L + t) << p.hshift)) + (n & ((1 << p.hshift) - 1)));
+    };
+    auto gran = [&](int gt, int t) -> unsigned {                  // granule index of (this lane, tile mt = 0) in slab (gt, t)
+        return (unsigned)(((((size_t)dir * p.NT + gt) * p.L + t) * (H / 4) + uw / 4 + lh) * 32 + lr);
+    };
+    u32x4_t hq[NLD];
+    u32x2_t xq[MT][4];
+    u32x4_t cq[MT];
+    u32x4_t gpk[MT][2], cpk[MT];                                   // saved activations of the previous item, not yet stored
+#pragma unroll
+    for (int c = 0; c < NLD; ++c) hq[c] = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { cq[mt] = u32x4_t{0u, 0u, 0u, 0u}; cpk[mt] = cq[mt]; gpk[mt][0] = cq[mt]; gpk[mt][1] = cq[mt]; }
+    unsigned goff_p = OOB;                                         // granule of the previous item (OOB: none)
+    {   // input projection of item 0
+        const int t0 = dir ? p.L - 1 : 0, n = tile0 * 32 + lr;
+        const bool ok = n < p.N;
+        const unsigned bx = ok ? ((row_base(n, t0) * 2u + dir) * (unsigned)G4 + uw + 4 * lh) * 2u : OOB;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                xq[mt][g] = __builtin_amdgcn_raw_buffer_load_b64(rx, ok ? bx + (unsigned)(g * H + mt * 8) * 2u : OOB, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // nothing in flight at the loop's entry
+
+    const int Q = p.L * ntile;
+    int s = 0, tl = 0, pend_tl = -1;
+    for (int q = 0; q < Q; ++q) {
+        const int t = dir ? p.L - 1 - s : s;
+        const int gt = tile0 + tl;
+        int s1 = s, tl1 = tl + 1;
+        if (tl1 == ntile) { tl1 = 0; ++s1; }
+        int s2 = s1, tl2 = tl1 + 1;
+        if (tl2 == ntile) { tl2 = 0; ++s2; }
+        const int t1 = dir ? p.L - 1 - s1 : s1, t2 = dir ? p.L - 1 - s2 : s2;
+        STAMP(0);
+        __builtin_amdgcn_s_waitcnt((NST & 15) | ((NST >> 4) << 14) | 0x0F70);      // all but the h stores just issued
+        __syncthreads();                                           // B1: this item's tile is in LDS, hst is free
+        STAMP(1);
+        const bf16* hcur = hbuf + (q & 1) * (32 * LDH);
+        bf16* hnext = hbuf + ((q + 1) & 1) * (32 * LDH);
+        f32x16_t acc[MT];
+        float4 cprev[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[mt][g * 4 + 0] = lo_bf(xq[mt][g][0]); acc[mt][g * 4 + 1] = hi_bf(xq[mt][g][0]);
+                acc[mt][g * 4 + 2] = lo_bf(xq[mt][g][1]); acc[mt][g * 4 + 3] = hi_bf(xq[mt][g][1]);
+            }
+            cprev[mt] = s > 0 ? __builtin_bit_cast(float4, cq[mt]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        asm volatile("" ::: "memory");
+        // counter of item q + 2, read now and checked when its tile is requested
+        unsigned pv = __hip_atomic_load(cnt0 + (size_t)tl2 * SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // per-item addresses of what the MFMA loop issues
+        const bool v1 = q + 1 < Q, v2 = q + 2 < Q && s2 > 0;
+        const int n1 = (tile0 + tl1) * 32 + lr;
+        const unsigned bx1 = (v1 && n1 < p.N) ? ((row_base(n1, t1) * 2u + dir) * (unsigned)G4 + uw + 4 * lh) * 2u : OOB;
+        const unsigned bc1 = (v1 && s1 > 0) ? gran(tile0 + tl1, dir ? t1 + 1 : t1 - 1) * 16u : OOB;
+        const unsigned gcur = gran(gt, t);
+        STAMP(2);
+        {
+            constexpr int BD = 4;
+            const bf16* hb = hcur + lr * LDH + lh * 8;
+            s16x8_t bq[BD];
+#pragma unroll
+            for (int d = 0; d < BD; ++d) bq[d] = *reinterpret_cast<const s16x8_t*>(hb + d * 16);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8_t b = bq[ks % BD];
+                if (ks + BD < KS) bq[ks % BD] = *reinterpret_cast<const s16x8_t*>(hb + (ks + BD) * 16);
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    if (a * KS / NA != ks) continue;
+                    if (a < A_X) {                                 // h_{q+1}: registers -> the other LDS buffer
+                        const int c = a, idx = tid + 256 * c, row = idx / CPRH, part = idx - row * CPRH;
+                        *reinterpret_cast<u32x4_t*>(hnext + row * LDH + part * 8) = hq[c];
+                    } else if (a < A_C) {                          // input projection of item q + 1
+                        const int i = a - A_X, mt = i / 4, g = i % 4;
+                        xq[mt][g] = __builtin_amdgcn_raw_buffer_load_b64(rx, bx1 == OOB ? OOB : bx1 + (unsigned)(g * H + mt * 8) * 2u, 0, 0);
+                    } else if (a < A_H) {                          // c_{t-1} of item q + 1
+                        const int mt = a - A_C;
+                        cq[mt] = __builtin_amdgcn_raw_buffer_load_b128(rc, bc1 == OOB ? OOB : bc1 + (unsigned)(mt * 2 * 32 * 16), 0, 0);
+                    } else if (a < A_PC) {                         // h tile of item q + 2
+                        const int c = a - A_H;
+                        if (c == 0) {
+                            asm volatile("" : "+v"(pv));           // the counter is looked at HERE, not where it was read
+                            if (v2 && pv < (unsigned)(G * s2)) rs_wait(cnt0 + (size_t)tl2 * SYNC_STRIDE, (unsigned)(G * s2), status, dead);
+                        }
+                        const int idx = tid + 256 * c, row = idx / CPRH, part = idx - row * CPRH, n = (tile0 + tl2) * 32 + row;
+                        const unsigned off = (v2 && n < p.N) ? ((row_base(n, dir ? t2 + 1 : t2 - 1) * 2u + dir) * (unsigned)H + part * 8) * 2u : OOB;
+                        hq[c] = __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 16);
+                    } else if (a < A_PG) {                         // saved c of item q - 1
+                        const int mt = a - A_PC;
+                        __builtin_amdgcn_raw_buffer_store_b128(cpk[mt], rc, goff_p == OOB ? OOB : (goff_p + (unsigned)(mt * 2 * 32)) * 16u, 0, 0);
+                    } else {                                       // saved gates of item q - 1
+                        const int i = a - A_PG, mt = i / 2, hf = i % 2;
+                        __builtin_amdgcn_raw_buffer_store_b128(gpk[mt][hf], rgt, goff_p == OOB ? OOB : (goff_p + (unsigned)(mt * 2 * 32)) * 32u + hf * 16u, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mfma_wa(acc[mt], w[mt][ks], b);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfma_drain(acc);
+        }
+        STAMP(3);
+        // ---- the previous item's h stores are older than everything the loop issued: counted drain, then its signal
+        __builtin_amdgcn_s_waitcnt((NDUR & 15) | ((NDUR >> 4) << 14) | 0x0F70);
+        asm volatile("" ::: "memory");
+        STAMP(4);
+        if (pend_tl >= 0) {
+            __syncthreads();                                       // B3
+            if (tid == 0) __hip_atomic_fetch_add(cnt0 + (size_t)pend_tl * SYNC_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        STAMP(5);
+        // ---- gates and state update
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float gi[4], gf[4], gg[4], go[4], hv[4];
+            float4 cnew;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                gi[u] = sigm_r(acc[mt][u]); gf[u] = sigm_r(acc[mt][4 + u]);
+                gg[u] = tanh_r(acc[mt][8 + u]); go[u] = sigm_r(acc[mt][12 + u]);
+                const float c = gf[u] * (&cprev[mt].x)[u] + gi[u] * gg[u];
+                (&cnew.x)[u] = c;
+                hv[u] = go[u] * tanh_r(c);
+            }
+            cpk[mt] = __builtin_bit_cast(u32x4_t, cnew);
+            u32x2_t hp;
+            hp[0] = pack_bf16x2(hv[0], hv[1]); hp[1] = pack_bf16x2(hv[2], hv[3]);
+            *reinterpret_cast<u32x2_t*>(hst + lr * LDST + wave * 8 * MT + mt * 8 + 4 * lh) = hp;
+            gpk[mt][0][0] = pack_bf16x2(gi[0], gi[1]); gpk[mt][0][1] = pack_bf16x2(gi[2], gi[3]);
+            gpk[mt][0][2] = pack_bf16x2(gf[0], gf[1]); gpk[mt][0][3] = pack_bf16x2(gf[2], gf[3]);
+            gpk[mt][1][0] = pack_bf16x2(gg[0], gg[1]); gpk[mt][1][1] = pack_bf16x2(gg[2], gg[3]);
+            gpk[mt][1][2] = pack_bf16x2(go[0], go[1]); gpk[mt][1][3] = pack_bf16x2(go[2], go[3]);
+        }
+        goff_p = gcur;
+        STAMP(8);
+        __syncthreads();                                           // B2: the CU's slice of h_t is staged
+        STAMP(9);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < NST; ++c) {
+            const int idx = tid + 256 * c, row = idx / CPRU, part = idx - row * CPRU, n = gt * 32 + row;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(hst + row * LDST + part * 8);
+            const unsigned off = n < p.N ? ((row_base(n, t) * 2u + dir) * (unsigned)H + u0 + part * 8) * 2u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, off, 0, 16);
+        }
+        asm volatile("" ::: "memory");
+        pend_tl = s + 1 < p.L ? tl : -1;
+        STAMP(10);
+        s = s1; tl = tl1;
+    }
+    // the last item's saved activations
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        __builtin_amdgcn_raw_buffer_store_b128(cpk[mt], rc, (goff_p + (unsigned)(mt * 2 * 32)) * 16u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(gpk[mt][0], rgt, (goff_p + (unsigned)(mt * 2 * 32)) * 32u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(gpk[mt][1], rgt, (goff_p + (unsigned)(mt * 2 * 32)) * 32u + 16u, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward through time.  Per step  dh_t[n, u] = dy_t[n, u] + sum_k dG_{t+1}[n, k] W_hh[k][u]  (k over the 4H gate
 // columns), then the gate gradients of the units, published as the CU's 4U columns of the row-major dG buffer,
 // which is the exchange medium (the weight-gradient GEMMs read it afterwards anyway).
@@ -699,9 +918,14 @@ extern "C" int dtt_lstm_rs_fwd(const void* xg, const void* whh, void* y, void* g
 #define LAUNCH_RF(MTV, KSV, DP) do { auto k = lstm_rs_fwd_kernel<MTV, KSV, DP>; \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
-    const bool deep = NT / S >= 3;                          // the smallest cluster has floor(NT / S) tiles
-    if (H == 512) { if (deep) LAUNCH_RF(2, 32, true); else LAUNCH_RF(2, 32, false); }
-    else { if (deep) LAUNCH_RF(4, 16, true); else LAUNCH_RF(4, 16, false); }
+    const int tmin = NT / S;                                // the smallest cluster has floor(NT / S) tiles
+    DTT_CHECK((int64_t)2 * NT * L * H * 32 * 4 < (1LL << 31), "dtt_lstm_rs_fwd: saved activations exceed 31-bit byte offsets");
+#define LAUNCH_RD(MTV, KSV) do { auto k = lstm_rs_fwd_deep_kernel<MTV, KSV>; \
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
+    if (H == 512) { if (tmin >= 4) LAUNCH_RD(2, 32); else if (tmin == 3) LAUNCH_RF(2, 32, true); else LAUNCH_RF(2, 32, false); }
+    else { if (tmin >= 4) LAUNCH_RD(4, 16); else if (tmin == 3) LAUNCH_RF(4, 16, true); else LAUNCH_RF(4, 16, false); }
+#undef LAUNCH_RD
 #undef LAUNCH_RF
     DTT_LAUNCH_CHECK();
     return 0;

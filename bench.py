@@ -358,7 +358,8 @@ def _time_conv(ops, B, Fq, T, Cc, dt, dev, n=20):
 def _time_lstm(ops, B, g, seconds, dt, dev):
     """The time-axis recurrent forward pass of one TC_FC_RNN at the workload's latent size, through the C ABI:
     N = B * heads * 65 sequences of L = T/8 steps, C' = 8g (x-attn latent: 16g channels over 2 heads), H = 2C'.
-    The weight-stationary cluster kernel (lstm_cluster.hip) when it covers the shape, else the streaming kernel."""
+    The register-stationary kernel (lstm_rs.hip) at H = 512, the LDS-stationary cluster kernel (lstm_cluster.hip)
+    at the other widths it covers, else the streaming kernel."""
     import ctypes as C
     from dtt_amd._lib import lib, check, ptr, stream_ptr, dtype_code
     heads, Fq = 2, 65
@@ -369,8 +370,21 @@ def _time_lstm(ops, B, g, seconds, dt, dev):
     xg = (torch.randn(R, 8 * H, device=dev) * 0.5).to(dt)
     whh = torch.randn(2, 4 * H, H, device=dev) / H ** 0.5
     y = torch.empty(R, 2 * H, device=dev, dtype=dt)
-    geom = ops._cluster_geometry(N, H, d)
-    if geom is not None:
+    rs = ops._rs_ok(N, H, d, heads, "auto")
+    geom = None if rs else ops._cluster_geometry(N, H, d)
+    if rs:
+        NT = (N + 31) // 32
+        wt = whh.to(dt).contiguous()
+        gates = torch.empty(2, NT, L, 4 * H * 32, device=dev, dtype=dt)
+        cst = torch.empty(2, NT, L, H * 32, device=dev, dtype=torch.float32)
+        sync = torch.empty(lib().dtt_lstm_rs_sync_words(N, H), device=dev, dtype=torch.int32)
+        name = ("lstm_rs_fwd_deep_kernel (dtt_lstm_rs_fwd: BiLSTM recurrence, W_hh resident in the AGPRs of 8-CU "
+                "clusters, h tile once per CU through LDS")
+
+        def launch():
+            check(lib().dtt_lstm_rs_fwd(ptr(xg), ptr(wt), ptr(y), ptr(gates), ptr(cst), ptr(sync), N, L, heads, H, d,
+                                        stream_ptr()), "dtt_lstm_rs_fwd")
+    elif geom is not None:
         NT = (N + 31) // 32
         wt = whh.to(dt).contiguous()
         gates = torch.empty(2, NT, L, 4 * H * 32, device=dev, dtype=dt)

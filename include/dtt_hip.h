@@ -181,6 +181,21 @@ int dtt_lstm_rs_bwd(const void* dy, const void* gates_blk, const float* cst_blk,
                     float* dcbuf, float* dbias, unsigned* sync, int N, int L, int heads, int H, int dtype,
                     void* stream);
 
+/* Every derived weight tensor of a step in one launch: the casts / permuted / stacked / transposed copies of
+ * parameters that the reference's modules get from autocast and from PyTorch's own weight layouts
+ * (block_tfc_tdf.py:12-32 conv weights, latent.py:87-96 LSTM / Linear weights, ...) are strided copies with an
+ * optional fp32 -> bf16 cast.  descs: device table; chunks: device table of int32 pairs (descriptor index, chunk
+ * index), one workgroup each, dtt_multi_pack_chunk() elements per chunk, row-major over `shape`. */
+typedef struct DttPackDesc {
+    const void* src; void* dst;
+    int64_t sstride[4], dstride[4];   /* element strides */
+    int64_t numel;
+    int32_t shape[4];
+    int32_t src_dtype, dst_dtype;     /* 0 = float32, 1 = bfloat16 */
+} DttPackDesc;
+int dtt_multi_pack_chunk(void);
+int dtt_multi_pack(const DttPackDesc* descs, const int32_t* chunks, int nchunks, void* stream);
+
 /* ---------------------------------------------------------------------------
  * STFT / iSTFT glue (base_dataset.py:154-167; model_dttnet.py:77-85), the 1x1
  * input conv (encoder.py:26-27) and the fused out conv + mask + torch.polar

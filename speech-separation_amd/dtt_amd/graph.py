@@ -24,6 +24,8 @@ replay, eagerly.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -57,7 +59,7 @@ class GraphedTrainStep:
     (collate.py:72-83), e.g. by running the GPU STFT; it is recorded with the rest.  ``inputs`` is any
     nest of CUDA tensors with the shapes every later batch will have."""
 
-    def __init__(self, model, criterion, optimizer, inputs, batch_fn, reducer=None, warmup=2):
+    def __init__(self, model, criterion, optimizer, inputs, batch_fn, reducer=None, warmup=2, pack_plan=None):
         if not torch.cuda.is_available():
             raise DttError("GraphedTrainStep needs an MI355X")
         self.model, self.criterion, self.opt, self.reducer = model, criterion, optimizer, reducer
@@ -69,6 +71,12 @@ class GraphedTrainStep:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.graph = torch.cuda.CUDAGraph()
         self._replays = 0
+        # derived weight tensors from one launch per step (ops._PackPlan), recorded by the first warm-up step.  Opt-in
+        # (pack_plan=True or DTT_PACK_PLAN=1): measured on cfg4 the graph replay does not get faster (47.3 ms with the
+        # plan, 46.5 without: ~400 tiny launches cost ~2 us each inside a graph, the table-driven kernel 0.5 ms)
+        if pack_plan is None:
+            pack_plan = os.environ.get("DTT_PACK_PLAN", "0") == "1"
+        ops.weight_plan(pack_plan)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager warm-up on the side stream (torch's recipe):
@@ -78,13 +86,14 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         if hasattr(optimizer, "prepare"):
             optimizer.prepare()
+        ops.finalize_packs()
         for p in self.params:
             p.grad = None
         ops.reset_zero_arena()                             # zero-filled scratch must be born inside the capture
         if reducer is not None:
             reducer.pause_hooks(True)
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may query events
                 loss = self._fwd_bwd()
                 if self.world == 1:
                     self.opt.step()
@@ -102,6 +111,7 @@ class GraphedTrainStep:
         batch.update(self.model(**batch))
         batch.update(self.criterion(**batch))
         batch["loss"].backward()
+        ops.join_packs()
         return batch["loss"]
 
     def _eager_once(self, step_opt):

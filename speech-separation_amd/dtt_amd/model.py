@@ -287,6 +287,7 @@ class DTTNetModel(_SeparatorBase):
 
     def forward(self, spectrogram, phase, audio_length, **batch):
         self._check(spectrogram)
+        ops.prepare_packs()
         x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
         x = self.latent(x)
         x = self.decoder(x, skips)
@@ -329,6 +330,7 @@ class DTTNetVisionModel(_SeparatorBase):
 
     def forward(self, spectrogram, video, phase, audio_length, video_features=None, **batch):
         self._check(spectrogram)
+        ops.prepare_packs()
         x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
         if video_features is None:                      # (tests may feed encoder outputs directly)
             video_features = self.encode_video(video)
@@ -364,6 +366,7 @@ class DTTNetPlusModel(_SeparatorBase):
         callers that cache the frozen encoder's output: ``video_features`` [B,T_v,2048] (ahead of the trainable
         post_processor) or ``video_encoded`` [B,T_v,D] (behind it)."""
         self._check(spectrogram)
+        ops.prepare_packs()
         x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
         if video_encoded is None:
             if video_features is None:

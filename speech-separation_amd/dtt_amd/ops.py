@@ -239,23 +239,182 @@ def _cast_perm(w, perm, dt):
     return out
 
 
+# --------------------------------------------------------------------------- #
+# Pack plan: every derived weight tensor of a step from ONE launch
+# --------------------------------------------------------------------------- #
+class DttPackDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("sstride", C.c_int64 * 4), ("dstride", C.c_int64 * 4),
+                ("numel", C.c_int64), ("shape", C.c_int32 * 4), ("src_dtype", C.c_int32), ("dst_dtype", C.c_int32)]
+
+
+def _merge_dims(shape, ss, ds):
+    """Drop size-1 dims and merge neighbours that are contiguous in BOTH views."""
+    dims = [(n, a, b) for n, a, b in zip(shape, ss, ds) if n != 1]
+    out = []
+    for n, a, b in dims:
+        if out and out[-1][1] == a * n and out[-1][2] == b * n:
+            out[-1] = (out[-1][0] * n, a, b)
+        else:
+            out.append((n, a, b))
+    return out or [(1, 1, 1)]
+
+
+class _PackPlan:
+    """A training step derives ~400 small tensors from its parameters (bf16 casts, conv weights in tap-major
+    order, stacked / transposed LSTM weights, padded TDF weights, ...): one 5 us launch each, strung between
+    the big kernels of the step (2.3 ms of a 47 ms step, in a HIP graph too).  Nearly all of them are strided
+    copies with a cast.  With the plan enabled, the first step records each as descriptors (source view ->
+    view of a PERSISTENT destination buffer) and `prepare` (called by the models' forward) refreshes all the
+    buffers with one dtt_multi_pack launch (pack.hip); the few recipes that are not plain copies (bias sums)
+    run as recorded closures right behind it.  Recipes read the parameters as they are when `prepare` runs:
+    parameters must not change between the start of forward and the end of backward, nor move in memory while
+    the plan is enabled (training loops satisfy this; weight_plan() forgets the plan).  Off by default, and
+    measured NOT to pay under graph replay yet: inside a HIP graph a tiny launch costs ~2 us, not the 5-7 us the
+    eager trace shows, and the table-driven kernel takes 0.5 ms (strided 4-byte reads of the transposed /
+    tap-major copies): cfg4 47.3 ms/step with the plan, 46.5 without.
+    (A first form ran the recipes on a side stream joined in stages: as a branch of the step's HIP graph it
+    made the replay 0.9 ms SLOWER than the chain of tiny launches it removed.)"""
+
+    def __init__(self):
+        self.enabled = False
+        self.outs = {}          # key -> persistent packed tensor
+        self.pairs = []         # (dst view, src view) of every recorded copy
+        self.closures = {}      # key -> recipe that is not a plain copy
+        self.fresh = {}         # key -> this step's result of a closure
+        self.table = None       # (descs on device, chunks on device, nchunks), rebuilt when pairs grow
+        self.ntab = 0
+
+    def reset(self, enabled):
+        self.__init__()
+        self.enabled = enabled
+
+    def build(self):
+        chunk = lib().dtt_multi_pack_chunk()
+        descs, chunks = [], []
+        for d, v in self.pairs:
+            dims = _merge_dims(v.shape, v.stride(), d.stride())
+            dims = [(1, 0, 0)] * (4 - len(dims)) + dims
+            e = DttPackDesc()
+            e.src, e.dst = v.data_ptr(), d.data_ptr()
+            for i, (n, a, b) in enumerate(dims):
+                e.shape[i], e.sstride[i], e.dstride[i] = n, a, b
+            e.numel = v.numel()
+            e.src_dtype, e.dst_dtype = dtype_code(v.dtype), dtype_code(d.dtype)
+            for c in range(-(-v.numel() // chunk)):
+                chunks += [len(descs), c]
+            descs.append(e)
+        arr = (DttPackDesc * len(descs))(*descs)
+        dev = self.pairs[0][0].device
+        dt_ = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        ct_ = torch.tensor(chunks, dtype=torch.int32).to(dev)
+        self.table, self.ntab = (dt_, ct_, len(chunks) // 2), len(self.pairs)
+
+
+_PLAN = _PackPlan()
+
+
+def weight_plan(enabled=True):
+    """Enable / disable (and forget) the pack plan."""
+    _PLAN.reset(bool(enabled))
+
+
+def prepare_packs():
+    """Refresh every recorded packed tensor (start of a training step; a no-op when the plan is off or empty).
+    Called by the models' forward."""
+    pl = _PLAN
+    if not pl.enabled:
+        return
+    if pl.pairs:
+        if pl.table is None or pl.ntab != len(pl.pairs):
+            if torch.cuda.is_current_stream_capturing():
+                raise DttError("pack plan: new packed tensors were recorded after the table was built; run one eager "
+                               "step and ops.finalize_packs() before capturing")
+            pl.build()
+        descs, chunks, n = pl.table
+        check(lib().dtt_multi_pack(ptr(descs), ptr(chunks), n, stream_ptr()), "dtt_multi_pack")
+    with torch.no_grad():
+        pl.fresh = {k: fn() for k, fn in pl.closures.items()}
+
+
+def finalize_packs():
+    """Build the descriptor table of everything recorded so far (host -> device copies: call it outside a stream
+    capture, as GraphedTrainStep does after its warm-up steps)."""
+    pl = _PLAN
+    if pl.enabled and pl.pairs and (pl.table is None or pl.ntab != len(pl.pairs)):
+        pl.build()
+
+
+def join_packs():
+    """(Kept for callers of the first, side-stream form of the plan: nothing to join any more.)"""
+    return None
+
+
+def packed(key, recipe, spec=None):
+    """The tensor `recipe()` derives from parameters.  With the plan enabled and `spec` = (shape, dtype,
+    pairs(out) -> [(view of out, source view of the same shape), ...]) it is a persistent buffer refreshed by
+    prepare_packs(); without a spec the recipe is re-run by prepare_packs()."""
+    pl = _PLAN
+    if not pl.enabled:
+        return recipe()
+    out = pl.outs.get(key)
+    if out is not None:
+        return out
+    if key in pl.fresh:
+        return pl.fresh[key]
+    if spec is not None:
+        shape, dt, pairs = spec
+        with torch.no_grad():
+            # destination first (zeros: padding stays zero for good), then the copies of the recording step
+            out = torch.zeros(shape, dtype=dt, device=torch.device("cuda", torch.cuda.current_device()))
+            pr = pairs(out)
+            if all(d.shape == v.shape and len(_merge_dims(v.shape, v.stride(), d.stride())) <= 4 for d, v in pr):
+                for d, v in pr:
+                    d.copy_(v)
+                pl.pairs += pr
+                pl.outs[key] = out
+                return out
+    v = recipe()
+    pl.closures[key] = recipe
+    pl.fresh[key] = v
+    return v
+
+
+def _pp(tag, w, perm, dt):
+    """_cast_perm(w, perm, dt) through the plan."""
+    shape = tuple(w.shape[i] for i in perm)
+    return packed(_wkey(tag, dt, w), lambda: _cast_perm(w, perm, dt), (shape, dt, lambda out: [(out, w.permute(*perm))]))
+
+
+def _wkey(tag, dt, *ws):
+    return (tag, dt) + tuple(w.data_ptr() for w in ws)
+
+
 def _pack_fwd(w, kind, dt):
     if kind == "up":      # ConvTranspose2d weight [Ci, Co, 3, 3]
-        return _cast_perm(w, (1, 2, 3, 0), dt).view(w.shape[1], -1)
-    return _cast_perm(w, (0, 2, 3, 1), dt).view(w.shape[0], -1)
+        return _pp("pfup", w, (1, 2, 3, 0), dt).view(w.shape[1], -1)
+    return _pp("pf", w, (0, 2, 3, 1), dt).view(w.shape[0], -1)
+
+
+def _pack_dgrad_s1_now(w, dt):
+    if w.dtype == F32 and w.is_contiguous() and w.shape[2:] == (3, 3):
+        out = torch.empty((w.shape[1], 9 * w.shape[0]), dtype=dt, device=w.device)
+        check(lib().dtt_pack_conv3_dgrad(ptr(w), ptr(out), w.shape[0], w.shape[1], 1 if dt == torch.bfloat16 else 0,
+                                         stream_ptr()), "dtt_pack_conv3_dgrad")
+        return out
+    return _cast_perm(w.flip(2, 3), (1, 2, 3, 0), dt).view(w.shape[1], -1)
 
 
 def _pack_dgrad(w, kind, dt):
-    if kind == "s1":
-        if w.dtype == F32 and w.is_contiguous() and w.shape[2:] == (3, 3):
-            out = torch.empty((w.shape[1], 9 * w.shape[0]), dtype=dt, device=w.device)
-            check(lib().dtt_pack_conv3_dgrad(ptr(w), ptr(out), w.shape[0], w.shape[1], 1 if dt == torch.bfloat16 else 0,
-                                             stream_ptr()), "dtt_pack_conv3_dgrad")
-            return out
-        return _cast_perm(w.flip(2, 3), (1, 2, 3, 0), dt).view(w.shape[1], -1)
+    if kind == "s1":      # out[ci][kh][kw][co] = w[co][ci][2-kh][2-kw]: taps rotated, channels swapped
+        Co, Ci = w.shape[0], w.shape[1]
+
+        def pairs(out):
+            o4 = out.view(Ci, 3, 3, Co)
+            return [(o4[:, kh, kw, :], w[:, :, 2 - kh, 2 - kw].t()) for kh in range(3) for kw in range(3)]
+        return packed(_wkey("pds1", dt, w), lambda: _pack_dgrad_s1_now(w, dt), ((Ci, 9 * Co), dt, pairs))
     if kind == "down":
-        return _cast_perm(w, (1, 2, 3, 0), dt).view(w.shape[1], -1)
-    return _cast_perm(w, (0, 2, 3, 1), dt).view(w.shape[0], -1)                    # up: [Ci][tap][Co]
+        return _pp("pddown", w, (1, 2, 3, 0), dt).view(w.shape[1], -1)
+    return _pp("pdup", w, (0, 2, 3, 1), dt).view(w.shape[0], -1)                    # up: [Ci][tap][Co]
 
 
 def _conv_backward(kind, x, w, dy, need_dx):
@@ -354,9 +513,12 @@ class TDF(torch.autograd.Function):
         N = T * Cc
         dt = x.dtype
         Fp = (Fq + 7) // 8 * 8
-        w1p = torch.zeros(J, Fp, dtype=dt, device=x.device)
-        w1p[:, :Fq] = w1
-        w2p = w2.to(dt).contiguous()                        # [F][J]
+        def pad_w1():
+            t = torch.zeros(J, Fp, dtype=dt, device=x.device)
+            t[:, :Fq] = w1
+            return t
+        w1p = packed(_wkey("tdf1", dt, w1), pad_w1, ((J, Fp), dt, lambda out: [(out[:, :Fq], w1)]))
+        w2p = packed(_wkey("tdf2", dt, w2), lambda: w2.to(dt).contiguous(), (tuple(w2.shape), dt, lambda out: [(out, w2)]))   # [F][J]
         hid = _empty((B, J, N), dt, x.device)
         gemm_raw(A=w1p, B=x, C=hid, bias=b1, M=J, N=N, K=Fq, batch=B, a_ms=Fp, a_ks=1, a_bs=0, b_ks=N, b_ns=1,
                  b_bs=Fq * N, c_ms=N, c_ns=1, c_bs=J * N, dtype=_dt(x), bias_mode=2)
@@ -411,6 +573,20 @@ def _pack_whh_bwd(w, dt):
     """[4H, H] -> fragments of B[k][n] = W_hh[k][n] for dh = dG * W_hh: [H/32][4H/16][64][8]."""
     G4, H = w.shape
     return _cast_perm(w.view(G4 // 16, 2, 8, H // 32, 32), (3, 0, 1, 4, 2), dt)
+
+
+def _pack_pair(tag, wa, wb, dt, fwd):
+    """Both directions' weights in MFMA fragment order (_pack_whh_fwd / _pack_whh_bwd), stacked."""
+    G4, H = wa.shape
+    if fwd:
+        vw = lambda w: w.view(G4 // 32, 32, H // 16, 2, 8).permute(0, 2, 3, 1, 4)
+        fn = _pack_whh_fwd
+    else:
+        vw = lambda w: w.view(G4 // 16, 2, 8, H // 32, 32).permute(3, 0, 1, 4, 2)
+        fn = _pack_whh_bwd
+    shape = (2,) + tuple(vw(wa).shape)
+    return packed(_wkey(tag, dt, wa, wb), lambda: torch.stack([fn(wa, dt), fn(wb, dt)]).contiguous(),
+                  (shape, dt, lambda out: [(out[0], vw(wa)), (out[1], vw(wb))]))
 
 
 def _unblock(t, W, N, L, heads):
@@ -477,8 +653,10 @@ class DualPathRNN(torch.autograd.Function):
         geo = (nslab, NI, L, Cc, Cp, gs, C.c_int64(OS), C.c_int64(IS), C.c_int64(RS))
         check(lib().dtt_gn_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(xn), ptr(xperm), ptr(gstats), *geo,
                                C.c_float(1e-5), d, stream_ptr()), "dtt_gn_fwd")
-        wih = torch.cat([w_ih, w_ih_r], 0).to(dt).contiguous()                 # [8H][Cp]
-        bsum = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r]).contiguous()
+        wih = packed(_wkey("wih", dt, w_ih, w_ih_r), lambda: torch.cat([w_ih, w_ih_r], 0).to(dt).contiguous(),
+                     ((8 * H, Cp), dt, lambda out: [(out[:4 * H], w_ih), (out[4 * H:], w_ih_r)]))    # [8H][Cp]
+        bsum = packed(_wkey("bsum", F32, b_ih, b_hh, b_ih_r, b_hh_r),
+                      lambda: torch.cat([b_ih + b_hh, b_ih_r + b_hh_r]).contiguous())
         y = _empty((R, 2 * H), dt, dev)
         need = any(ctx.needs_input_grad)
         N = nslab * heads
@@ -493,7 +671,8 @@ class DualPathRNN(torch.autograd.Function):
             gemm_raw(A=xn, B=wih, C=xg, bias=bsum, M=R, N=8 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=1, b_ns=Cp,
                      c_ms=8 * H, c_ns=1, dtype=d, bias_mode=1)
             NT = (N + 31) // 32
-            whh = torch.stack([w_hh, w_hh_r]).to(dt).contiguous()              # [2][4H][H]
+            whh = packed(_wkey("whh", dt, w_hh, w_hh_r), lambda: torch.stack([w_hh, w_hh_r]).to(dt).contiguous(),
+                         ((2, 4 * H, H), dt, lambda out: [(out[0], w_hh), (out[1], w_hh_r)]))   # [2][4H][H]
             gates = _empty((2, NT, L, 4 * H * 32), dt, dev) if need else None
             cst = _empty((2, NT, L, H * 32), F32, dev)
             sync = _empty((lib().dtt_lstm_rs_sync_words(N, H),), torch.int32, dev)
@@ -506,7 +685,8 @@ class DualPathRNN(torch.autograd.Function):
             gemm_raw(A=xn, B=wih, C=xg, bias=bsum, M=R, N=8 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=1, b_ns=Cp,
                      c_ms=8 * H, c_ns=1, dtype=d, bias_mode=1)
             NT = (N + 31) // 32
-            whh = torch.stack([w_hh, w_hh_r]).to(dt).contiguous()              # [2][4H][H]
+            whh = packed(_wkey("whh", dt, w_hh, w_hh_r), lambda: torch.stack([w_hh, w_hh_r]).to(dt).contiguous(),
+                         ((2, 4 * H, H), dt, lambda out: [(out[0], w_hh), (out[1], w_hh_r)]))   # [2][4H][H]
             gates = _empty((2, NT, L, 4 * H * 32), dt, dev) if need else None
             cst = _empty((2, NT, L, H * 32), F32, dev)
             sync = _empty((lib().dtt_lstm_cluster_sync_words(geom[2]),), torch.int32, dev)
@@ -515,8 +695,8 @@ class DualPathRNN(torch.autograd.Function):
         elif blocked:
             # fused input projection, activations saved in the kernels' private blocked layout
             nblk = (N + 31) // 32
-            wp = torch.stack([_pack_whh_fwd(w_hh, dt), _pack_whh_fwd(w_hh_r, dt)]).contiguous()
-            wihp = torch.stack([_pack_whh_fwd(w_ih, dt), _pack_whh_fwd(w_ih_r, dt)]).contiguous()
+            wp = _pack_pair("whhp", w_hh, w_hh_r, dt, True)
+            wihp = _pack_pair("wihp", w_ih, w_ih_r, dt, True)
             gates = _empty((2, nblk, L, 4 * H * 32), dt, dev) if need else None
             cst = _empty((2, nblk, L, H * 32), F32, dev) if need else None
             rc = lib().dtt_lstm_fwd_fused(ptr(xn), ptr(wihp), ptr(wp), ptr(bsum), ptr(y), ptr(gates), ptr(cst), N, L,
@@ -531,10 +711,11 @@ class DualPathRNN(torch.autograd.Function):
                      c_ms=8 * H, c_ns=1, dtype=d, bias_mode=1)
             gates = _empty((R, 2, 4 * H), dt, dev) if need else None
             cst = _empty((R, 2, H), F32, dev)            # always: the cell state round-trips through it
-            wp = torch.stack([_pack_whh_fwd(w_hh, dt), _pack_whh_fwd(w_hh_r, dt)]).contiguous()
+            wp = _pack_pair("whhp", w_hh, w_hh_r, dt, True)
             check(lib().dtt_lstm_fwd(ptr(xg), ptr(wp), ptr(y), ptr(gates), ptr(cst), N, L, heads, H, d, stream_ptr()),
                   "dtt_lstm_fwd")
-        fcw = fc_w.to(dt).contiguous()                                         # [Cp][4Cp]
+        fcw = packed(_wkey("fcw", dt, fc_w), lambda: fc_w.to(dt).contiguous(),
+                     (tuple(fc_w.shape), dt, lambda out: [(out, fc_w)]))                     # [Cp][4Cp]
         res = xperm if along_f else x
         out = _empty((nslab, L, Cc), dt, dev)
         gemm_raw(A=y, B=fcw, C=out, bias=fc_b, R=res, M=R, N=Cp, K=2 * H, a_ms=2 * H, a_ks=1, b_ks=1, b_ns=2 * H,
@@ -570,7 +751,8 @@ class DualPathRNN(torch.autograd.Function):
         if rs:
             N = nslab * heads
             NT = (N + 31) // 32
-            whhT = torch.stack([w_hh.t(), w_hh_r.t()]).to(dt).contiguous()     # [2][H][4H]
+            whhT = packed(_wkey("whhT", dt, w_hh, w_hh_r), lambda: torch.stack([w_hh.t(), w_hh_r.t()]).to(dt).contiguous(),
+                          ((2, H, 4 * H), dt, lambda out: [(out[0], w_hh.t()), (out[1], w_hh_r.t())]))   # [2][H][4H]
             dcbuf = _empty((2, NT, H * 32), F32, dev)
             dbias = _zeros_f32((2 * 4 * H,), dev)
             sync = _empty((lib().dtt_lstm_rs_sync_words(N, H),), torch.int32, dev)
@@ -579,19 +761,20 @@ class DualPathRNN(torch.autograd.Function):
         elif geom is not None:
             N = nslab * heads
             NT = (N + 31) // 32
-            whhT = torch.stack([w_hh.t(), w_hh_r.t()]).to(dt).contiguous()     # [2][H][4H]
+            whhT = packed(_wkey("whhT", dt, w_hh, w_hh_r), lambda: torch.stack([w_hh.t(), w_hh_r.t()]).to(dt).contiguous(),
+                          ((2, H, 4 * H), dt, lambda out: [(out[0], w_hh.t()), (out[1], w_hh_r.t())]))   # [2][H][4H]
             dcbuf = _empty((2, NT, H * 32), F32, dev)
             dbias = _zeros_f32((2 * 4 * H,), dev)
             sync = _empty((lib().dtt_lstm_cluster_sync_words(geom[2]),), torch.int32, dev)
             check(lib().dtt_lstm_cluster_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(whhT), ptr(dG), ptr(dcbuf), ptr(dbias),
                                              ptr(sync), N, L, heads, H, d, stream_ptr()), "dtt_lstm_cluster_bwd")
         elif blocked:
-            wpt = torch.stack([_pack_whh_bwd(w_hh, dt), _pack_whh_bwd(w_hh_r, dt)]).contiguous()
+            wpt = _pack_pair("whhpt", w_hh, w_hh_r, dt, False)
             dbias = _zeros_f32((2 * 4 * H,), dev)           # bias gradient accumulated inside the kernel
             check(lib().dtt_lstm_bwd_blk(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), ptr(dbias), nslab * heads,
                                          L, heads, H, d, stream_ptr()), "dtt_lstm_bwd_blk")
         else:
-            wpt = torch.stack([_pack_whh_bwd(w_hh, dt), _pack_whh_bwd(w_hh_r, dt)]).contiguous()
+            wpt = _pack_pair("whhpt", w_hh, w_hh_r, dt, False)
             check(lib().dtt_lstm_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), nslab * heads, L, heads, H, d,
                                      stream_ptr()), "dtt_lstm_bwd")
         G4 = 4 * H
@@ -900,7 +1083,8 @@ class Conv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         Co, Ci = w.shape[0], w.shape[1]
-        wp = w.reshape(Co, Ci).to(x.dtype).contiguous()
+        wp = packed(_wkey("c1", x.dtype, w), lambda: w.reshape(Co, Ci).to(x.dtype).contiguous(),
+                    ((Co, Ci), x.dtype, lambda out: [(out, w.reshape(Co, Ci))]))
         y = _empty(x.shape[:-1] + (Co,), x.dtype, x.device)
         _linear_fwd(x.reshape(-1, Ci), wp, b, y.view(-1, Co))
         ctx.save_for_backward(x, wp)
@@ -924,7 +1108,8 @@ class Conv1x1NormGelu(torch.autograd.Function):
     def forward(ctx, x, w, b):
         B, Fq, T, Ci = x.shape
         Co = w.shape[0]
-        wp = w.reshape(Co, Ci).to(x.dtype).contiguous()
+        wp = packed(_wkey("c1", x.dtype, w), lambda: w.reshape(Co, Ci).to(x.dtype).contiguous(),
+                    ((Co, Ci), x.dtype, lambda out: [(out, w.reshape(Co, Ci))]))
         y = _empty((B, Fq, T, Co), x.dtype, x.device)
         _linear_fwd(x.view(-1, Ci), wp, b, y.view(-1, Co))
         stats = in_stats(y)
@@ -1116,7 +1301,8 @@ class Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, sigmoid):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        wt = w.to(x2.dtype).contiguous()
+        wt = packed(_wkey("lin", x2.dtype, w) + (w.storage_offset(), w.shape[0]), lambda: w.to(x2.dtype).contiguous(),
+                    (tuple(w.shape), x2.dtype, lambda out: [(out, w)]))
         y = _empty((x2.shape[0], wt.shape[0]), x2.dtype, x2.device)
         kw = dict(A=x2, B=wt, C=y, M=x2.shape[0], N=wt.shape[0], K=x2.shape[1], a_ms=x2.shape[1], a_ks=1, b_ks=1,
                   b_ns=x2.shape[1], c_ms=wt.shape[0], c_ns=1, dtype=_dt(x2), act=2 if sigmoid else 0)

@@ -52,3 +52,12 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _pack_plan_off():
+    """dtt_amd.GraphedTrainStep switches the process-wide pack plan (ops._PackPlan) on: never into the next test."""
+    yield
+    mod = sys.modules.get("dtt_amd.ops")
+    if mod is not None:
+        mod.weight_plan(False)

@@ -82,3 +82,47 @@ def test_graphed_step_follows_eager_step():
     assert float(torch.dot(de, dg) / (de.norm() * dg.norm())) > 0.97
     assert abs(float(dg.norm() / de.norm()) - 1) < 0.05
     assert float(o_g.state_dict()["state"][0]["step"]) == 4.0
+
+
+def test_pack_plan_matches_plain_steps():
+    """ops._PackPlan (derived weight tensors refreshed by one dtt_multi_pack launch per step): an eager
+    step with the plan recorded, replayed, and replayed after the parameters moved gives the loss and the
+    gradients of the same step without it (to the run-to-run noise of the fp32 atomics)."""
+    from dtt_amd import ops
+    model, _, crit = _setup(False)
+    s1, s2 = synth_sources(2, 800, seed=77)
+    inp = {"s1": s1.to(DEV), "s2": s2.to(DEV)}
+
+    def grads():
+        for p in model.parameters():
+            p.grad = None
+        b = _batch_fn(inp)
+        b.update(model(**b))
+        b.update(crit(**b))
+        b["loss"].backward()
+        ops.join_packs()
+        torch.cuda.synchronize()
+        return torch.cat([p.grad.reshape(-1) for p in model.parameters()]).double(), float(b["loss"])
+
+    def close(a, b):
+        return float((a - b).norm() / a.norm()) < 1e-5
+
+    ops.weight_plan(False)
+    g0, l0 = grads()
+    try:
+        ops.weight_plan(True)
+        g1, l1 = grads()                 # records
+        assert len(ops._PLAN.pairs) > 10
+        g2, l2 = grads()                 # refreshed by the one pack launch
+        assert ops._PLAN.table is not None and ops._PLAN.table[2] > 10
+        with torch.no_grad():            # the plan follows the parameters
+            for p in model.parameters():
+                p.mul_(1.01)
+        g3, l3 = grads()
+        ops.weight_plan(False)
+        g4, l4 = grads()
+    finally:
+        ops.weight_plan(False)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0) and abs(l0 - l2) <= 1e-6 * abs(l0) and abs(l3 - l4) <= 1e-6 * abs(l3)
+    assert abs(l3 - l0) > 1e-6 * abs(l0)
+    assert close(g0, g1) and close(g0, g2) and close(g4, g3)

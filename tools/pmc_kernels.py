@@ -1,5 +1,5 @@
 """Runs the roofline kernels of bench.py a few times so that rocprofv3 --pmc can count their HBM traffic:
-the weight-stationary recurrent kernel at the cfg4 time-axis shape (N = 2080, L = 16, H = 512), and the two 3x3
+the register-stationary recurrent kernel (lstm_rs.hip) at the cfg4 time-axis shape (N = 2080, L = 16, H = 512), and the two 3x3
 convs (64->64 at [B,257,63], 32->32 at [B,513,126]) at B = 16 (cfg4) and B = 64 (cfg2).
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_rd -- python3 tools/pmc_kernels.py
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_wr -- python3 tools/pmc_kernels.py
@@ -20,14 +20,13 @@ R = N * L
 xg = (torch.randn(R, 8 * H, device=dev) * 0.5).to(dt)
 whh = (torch.randn(2, 4 * H, H, device=dev) / H ** 0.5).to(dt).contiguous()
 y = torch.empty(R, 2 * H, device=dev, dtype=dt)
-geom = ops._cluster_geometry(N, H, d)
 NT = (N + 31) // 32
 gates = torch.empty(2, NT, L, 4 * H * 32, device=dev, dtype=dt)
 cst = torch.empty(2, NT, L, H * 32, device=dev, dtype=torch.float32)
-sync = torch.empty(lib().dtt_lstm_cluster_sync_words(geom[2]), device=dev, dtype=torch.int32)
+sync = torch.empty(lib().dtt_lstm_rs_sync_words(N, H), device=dev, dtype=torch.int32)
 for _ in range(5):
-    check(lib().dtt_lstm_cluster_fwd(ptr(xg), ptr(whh), ptr(y), ptr(gates), ptr(cst), ptr(sync), N, L, heads, H, d,
-                                     stream_ptr()), "dtt_lstm_cluster_fwd")
+    check(lib().dtt_lstm_rs_fwd(ptr(xg), ptr(whh), ptr(y), ptr(gates), ptr(cst), ptr(sync), N, L, heads, H, d,
+                                stream_ptr()), "dtt_lstm_rs_fwd")
 torch.cuda.synchronize()
 for B in (16, 64):
     for (Fq, T, Cc) in [(257, 63, 64), (513, 126, 32)]:

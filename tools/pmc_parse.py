@@ -30,7 +30,7 @@ def main():
     def groups(dd):
         g = collections.OrderedDict()
         for (did, name, grid), v in dd.items():
-            if "lstm_cluster_fwd" in name or "conv3x3_s1_kernel" in name or "conv3x3_c32_kernel" in name:
+            if "lstm_rs_fwd" in name or "lstm_cluster_fwd" in name or "conv3x3_s1_kernel" in name or "conv3x3_c32_kernel" in name:
                 short = re.sub(r"\(anonymous namespace\)::|^void ", "", name)
                 short = short[:short.rfind("(")] if "(" in short else short
                 g.setdefault((short, grid), []).append(v)
@@ -43,7 +43,7 @@ def main():
     for k, n in zip(convs, names):
         labels[k] = n
     for k in gr:
-        if "lstm_cluster_fwd" in k[0]:
+        if "lstm_rs_fwd" in k[0] or "lstm_cluster_fwd" in k[0]:
             labels[k] = "lstm_fwd_H512_N2080_L16"
     res, lines = {}, []
     for k, lab in labels.items():

@@ -588,15 +588,17 @@ template <int MTB, int KSB, bool DEEP>
 __global__ __launch_bounds__(256, 1) void lstm_rs_bwd_kernel(LstmRB p) {
     constexpr int H = KSB * 32, U = 16 * MTB, G = H / U, G4 = 4 * H, KQ = H;     // KQ: gate columns per wave
     constexpr int MW = MTB / 4;                   // tiles a wave finishes
-    constexpr int NLB = 2 * KSB;                  // B fragments per item: (k-step, 16-sequence half)
-    constexpr int W = NLB >= 32 ? 16 : 8;         // fragments in flight
+    constexpr int PPR = KQ / 8;                   // 16-byte pieces of a wave's quarter of one dG row
+    constexpr int NLH = 16 * PPR / 64;            // loads per lane for a 16-sequence half of the tile
+    constexpr int LDQ = KQ + 8;                   // staging row (elements)
     constexpr int LDG = 4 * U + 8;                // staging row (elements): 4 gates x U units
     constexpr int CPRG = 4 * U / 8;               // 16-byte pieces per staged row
     constexpr int NST = 32 * CPRG / 256;          // published pieces per lane
-    static_assert(MTB * KSB <= 64 && MTB == 4 && NLB % W == 0 && MW >= 1, "shape");
+    static_assert(MTB * KSB <= 64 && MTB == 4 && MW >= 1 && NLH >= 1, "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);                              // [4 waves][MTB][2][64]
     bf16* dgs = reinterpret_cast<bf16*>(smem + (size_t)4 * MTB * 2 * 64 * 16);    // [32][LDG]
+    bf16* stage = dgs + 32 * LDG + (size_t)(threadIdx.x >> 6) * 16 * LDQ;         // [4 waves][16][LDQ]: wave-private
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sq = lane & 15, rg = lane >> 4;
     int cg, sg, dir;
     rs_role(blockIdx.x, G, p.S, dir, sg, cg);
@@ -624,17 +626,26 @@ __global__ __launch_bounds__(256, 1) void lstm_rs_bwd_kernel(LstmRB p) {
     auto row_base = [&](int n, int t) -> unsigned {
         return (unsigned)(((((n >> p.hshift) * p.L + t) << p.hshift)) + (n & ((1 << p.hshift) - 1)));
     };
-    // byte offsets of this lane's B fragments (the two 16-sequence halves) of the dG tile published at step `tn`
-    auto frag_base = [&](int gt, int tn, bool valid, unsigned (&fb)[2]) {
+    // A wave needs only its quarter of the gate columns of a dG row.  Fetched in MFMA fragment order, neighbouring
+    // lanes would read DIFFERENT rows (4 cache lines per quad of lanes: the loop ran at 21 B/clk per CU, four times
+    // the MFMA time).  So the quarter-rows are fetched whole, one contiguous 16-byte piece per lane, parked in a
+    // wave-private LDS image (no barrier: one wave writes and reads it, LDS operations of a wave stay in order) and
+    // read back as fragments.  Half a tile (16 sequences) at a time: the next half is in flight in registers.
+    u32x4_t bq[NLH];
+    auto issue_half = [&](int gtx, int tn, bool valid, int hh) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = gt * 32 + nt * 16 + sq;
-            fb[nt] = (valid && n < p.N) ? ((row_base(n, tn) * 2u + dir) * (unsigned)G4 + wave * KQ + rg * 8) * 2u : OOB;
+        for (int c = 0; c < NLH; ++c) {
+            const int idx = lane + 64 * c, row = idx / PPR, piece = idx - row * PPR, n = gtx * 32 + hh * 16 + row;
+            const unsigned off = (valid && n < p.N) ? ((row_base(n, tn) * 2u + dir) * (unsigned)G4 + wave * KQ + piece * 8) * 2u : OOB;
+            bq[c] = __builtin_amdgcn_raw_buffer_load_b128(rg_, off, 0, 16);
         }
     };
-    auto ld_frag = [&](const unsigned (&fb)[2], int j) -> u32x4_t {                // j = 2 * ks + nt
-        const unsigned b = fb[j & 1];
-        return __builtin_amdgcn_raw_buffer_load_b128(rg_, b == OOB ? OOB : b + (unsigned)((j >> 1) * 64), 0, 16);
+    auto stage_half = [&]() {
+#pragma unroll
+        for (int c = 0; c < NLH; ++c) {
+            const int idx = lane + 64 * c, row = idx / PPR, piece = idx - row * PPR;
+            *reinterpret_cast<u32x4_t*>(stage + row * LDQ + piece * 8) = bq[c];
+        }
     };
     auto signal = [&](int tlx) {
         __syncthreads();
@@ -683,11 +694,9 @@ __global__ __launch_bounds__(256, 1) void lstm_rs_bwd_kernel(LstmRB p) {
     int s = p.L - 1, tl = 0;                                       // items walk the steps downwards
     int pend_tl = -1;
     unsigned pv = 0;
-    unsigned fb[2] = {OOB, OOB}, fbn[2] = {OOB, OOB};
-    u32x4_t bq[W];
-    // the window of the first item: nothing to fetch (its dh is dy alone), keep the registers defined
+    // the half in flight ahead of the first item: nothing to fetch (its dh is dy alone), keep the registers defined
 #pragma unroll
-    for (int d = 0; d < W; ++d) bq[d] = u32x4_t{0u, 0u, 0u, 0u};
+    for (int c = 0; c < NLH; ++c) bq[c] = u32x4_t{0u, 0u, 0u, 0u};
     for (int q = 0; q < Q; ++q) {
         const int t = dir ? p.L - 1 - s : s;
         const int tnext = dir ? t - 1 : t + 1;                    // the step processed one iteration of s earlier
@@ -697,20 +706,15 @@ __global__ __launch_bounds__(256, 1) void lstm_rs_bwd_kernel(LstmRB p) {
         if (tl1 == ntile) { tl1 = 0; --s1; }
         const bool has_next = q + 1 < Q;
         const bool next_first = s1 == p.L - 1;
+        const int t1 = dir ? p.L - 1 - s1 : s1;
         STAMP(0);
         issue_side(s, tl);
         if constexpr (DEEP) {
             // next item's counter, read ahead of its use (no round trip, no drain at the check)
             pv = __hip_atomic_load(cnt0 + (size_t)tl1 * SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            frag_base(tile0 + tl1, dir ? (dir ? p.L - 1 - s1 : s1) - 1 : (dir ? p.L - 1 - s1 : s1) + 1, has_next && !next_first, fbn);
-        } else {
-            if (!first) {
-                rs_wait(cnt0 + (size_t)tl * SYNC_STRIDE, (unsigned)(G * (p.L - 1 - s)), status, dead);
-                frag_base(gt, tnext, true, fb);
-#pragma unroll
-                for (int d = 0; d < W; ++d) bq[d] = ld_frag(fb, d);
-            }
-            fbn[0] = OOB; fbn[1] = OOB;
+        } else if (!first) {
+            rs_wait(cnt0 + (size_t)tl * SYNC_STRIDE, (unsigned)(G * (p.L - 1 - s)), status, dead);
+            issue_half(gt, tnext, true, 0);
         }
         STAMP(1);
         // ---- partial dh over this wave's quarter of the gate columns
@@ -721,29 +725,39 @@ __global__ __launch_bounds__(256, 1) void lstm_rs_bwd_kernel(LstmRB p) {
             for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (!first || DEEP) {
 #pragma unroll
-            for (int j = 0; j < NLB; ++j) {
-                const s16x8_t b = __builtin_bit_cast(s16x8_t, bq[j % W]);
+            for (int hh = 0; hh < 2; ++hh) {
                 if constexpr (DEEP) {
-                    if (j == NLB - W) {                            // the window is about to wrap into the next item
-                        if (has_next && !next_first && pv < (unsigned)(G * (p.L - 1 - s1)))
-                            rs_wait(cnt0 + (size_t)tl1 * SYNC_STRIDE, (unsigned)(G * (p.L - 1 - s1)), status, dead);
-                    }
-                    if (j == W && pend_tl >= 0) {                  // the previous item's stores have had W fragments' time
+                    if (hh == 1 && pend_tl >= 0) {                 // the previous item's stores have had half a tile's time
                         // counted: younger than its dG stores are its dc stores, this item's side loads, the counter
-                        // read and the W refills issued so far (every one of them issued unconditionally)
-                        constexpr int NY = MW * 2 + MW * 2 * 6 + 1 + W;
+                        // read and the loads of the second half (every one of them issued unconditionally)
+                        constexpr int NY = MW * 2 + MW * 2 * 6 + 1 + NLH;
                         __builtin_amdgcn_s_waitcnt((NY & 15) | ((NY >> 4) << 14) | 0x0F70);
                         signal(pend_tl);
                         pend_tl = -1;
                     }
                 }
-                if (j + W < NLB) bq[j % W] = ld_frag(fb, j + W);
-                else if (DEEP) bq[j % W] = ld_frag(fbn, j + W - NLB);
+                stage_half();
+                if (hh == 0) issue_half(gt, tnext, !first, 1);
+                else if (DEEP) {
+                    asm volatile("" : "+v"(pv));
+                    if (has_next && !next_first && pv < (unsigned)(G * (p.L - 1 - s1)))
+                        rs_wait(cnt0 + (size_t)tl1 * SYNC_STRIDE, (unsigned)(G * (p.L - 1 - s1)), status, dead);
+                    issue_half(tile0 + tl1, dir ? t1 - 1 : t1 + 1, has_next && !next_first, 0);
+                }
+                const bf16* sb = stage + sq * LDQ + rg * 8;
+                constexpr int BD = 4;                              // fragments read ahead of the MFMAs that use them
+                s16x8_t fq[BD];
 #pragma unroll
-                for (int mt = 0; mt < MTB; ++mt) mfma16_wa(acc[mt][j & 1], w[mt][j >> 1], b);
+                for (int d = 0; d < BD; ++d) fq[d] = *reinterpret_cast<const s16x8_t*>(sb + d * 32);
+#pragma unroll
+                for (int ks = 0; ks < KSB; ++ks) {
+                    const s16x8_t b = fq[ks % BD];
+                    if (ks + BD < KSB) fq[ks % BD] = *reinterpret_cast<const s16x8_t*>(sb + (ks + BD) * 32);
+#pragma unroll
+                    for (int mt = 0; mt < MTB; ++mt) mfma16_wa(acc[mt][hh], w[mt][ks], b);
+                }
             }
         }
-        if constexpr (DEEP) { fb[0] = fbn[0]; fb[1] = fbn[1]; }
         STAMP(2);
         // ---- sum the four waves' partials: every wave leaves its own in LDS, wave w collects its MW tiles
         {
@@ -947,7 +961,7 @@ extern "C" int dtt_lstm_rs_bwd(const void* dy, const void* gates_blk, const floa
     DTT_CHECK(hipMemsetAsync(sync, 0, (size_t)dtt_lstm_rs_sync_words(N, H) * 4, st) == hipSuccess, "dtt_lstm_rs_bwd: memset failed");
     const dim3 grid(2 * S * G), block(256);
     const int U = H / G, MTB = U / 16;
-    const size_t sm = (size_t)4 * MTB * 2 * 64 * 16 + (size_t)32 * (4 * U + 8) * 2;
+    const size_t sm = (size_t)4 * MTB * 2 * 64 * 16 + (size_t)32 * (4 * U + 8) * 2 + (size_t)4 * 16 * (H + 8) * 2;
 #define LAUNCH_RB(MTV, KSV, DP) do { auto k = lstm_rs_bwd_kernel<MTV, KSV, DP>; \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)

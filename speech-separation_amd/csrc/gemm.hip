@@ -795,6 +795,8 @@ template <typename T> int dispatch(const DttGemm& p, hipStream_t st) {
 
 }  // namespace
 
+int dtt_gemm256_try(const DttGemm& p, hipStream_t st);   // gemm256.hip
+
 extern "C" int dtt_gemm(const DttGemm* pp, void* stream) {
     DttGemm p = *pp;
     DTT_CHECK(p.A && p.B && p.C, "dtt_gemm: null operand");
@@ -826,7 +828,9 @@ extern "C" int dtt_gemm(const DttGemm* pp, void* stream) {
     }
     if (p.b_mode == 2) DTT_CHECK(p.sh_heads > 0 && p.sh_L > 0 && p.b_ns == 1, "dtt_gemm: bad shift params");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int rc = p.dtype == 1 ? dispatch_fast<bf16>(p, st) : dispatch_fast<float>(p, st);
+    int rc = dtt_gemm256_try(p, st);
+    if (rc != 1) return rc;
+    rc = p.dtype == 1 ? dispatch_fast<bf16>(p, st) : dispatch_fast<float>(p, st);
     if (rc != 1) return rc;
     return p.dtype == 1 ? dispatch<bf16>(p, st) : dispatch<float>(p, st);
 }

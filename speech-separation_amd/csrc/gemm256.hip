@@ -1,0 +1,172 @@
+// 256 x 256 x 64 bf16 GEMM for the large plain products of the step (A [M][K] and B [N][K] both contiguous along k,
+// C [M][N] contiguous along n): the LSTM input projections x W_ih^T (latent.py:87-92; M = 33 280, N = 4 096,
+// K = 256 at cfg4), the TC_FC_RNN output Linear (latent.py:93-96) and their likes.
+//
+// Why a second GEMM kernel.  gemm_fast_kernel (128 x 128 workgroup tiles, operands staged through registers into
+// LDS) sits at 0.20-0.25 of the MFMA peak on every one of these shapes, whatever the split: a 128 x 128 x 64 step
+// needs 32 KB of operands for 2 x 128 x 128 x 64 flop = 64 flop per byte, exactly the ratio of a CU's MFMA rate
+// (4 096 flop/clk) to its vector-memory path (64 B/clk) -- the tile is bandwidth-bound inside the CU before LDS
+// traffic is counted, and its ds_write_b128 stores (79 B/clk) take longer than its MFMAs.  Here:
+//   * 256 x 256 tile per workgroup (128 flop per operand byte), 8 waves = 2 per SIMD, wave tile 128 x 64
+//     (4 x 2 MFMA tiles of 32x32x16: 6 fragment reads per 8 MFMAs instead of 4 per 4);
+//   * operands go global -> LDS by LDS-DMA (no registers, no ds_write), two 64 KB stages, ONE barrier per k-step of 64:
+//     the DMA of step kt + 1 is issued before the MFMAs of step kt and waited for behind them;
+//   * LDS image [row][64 k] without padding (DMA writes 1 KB per wave-instruction contiguously): the 16-byte piece c
+//     of row r is stored at piece c ^ ((r >> 1) & 7) -- the lane's SOURCE address carries the swizzle -- which makes
+//     the fragment reads (16 rows x one piece per lane group) conflict-free.
+// Epilogue: bias[n], residual, bf16 or fp32 store, through an LDS slab per wave (16-byte stores along n).
+#include "common.h"
+#include "../../include/dtt_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;            // 64 KB
+constexpr int SLAB_W = 64 + 4;                             // epilogue slab row (floats)
+
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const DttGemm p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_n = (p.N + BN - 1) / BN, ntile = gridDim.x;
+    int tile = blockIdx.x;
+    {   // XCD-aware order: consecutive logical tiles (which share an A panel) run on one XCD
+        const int per = ntile / 8;
+        if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
+    }
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+
+    // ---- DMA sources: wave-instruction j of this wave fills rows (wave * 4 + j) * 8 .. + 8 of a 256-row image
+    const bf16* pa[4];
+    const bf16* pb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int L = (wave * 4 + j) * 64 + lane, row = L >> 3, pos = L & 7, piece = pos ^ ((row >> 1) & 7);
+        pa[j] = A + (int64_t)min(m0 + row, p.M - 1) * p.a_ms + piece * 8;
+        pb[j] = B + (int64_t)min(n0 + row, p.N - 1) * p.b_ns + piece * 8;
+    }
+    auto issue = [&](int stage) {
+        unsigned char* sa = smem + stage * STAGE_BYTES + (wave * 4) * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)pa[j], (lptr_t)(sa + j * 1024), 16, 0, 0);
+            pa[j] += BK;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)pb[j], (lptr_t)(sa + BM * BK * 2 + j * 1024), 16, 0, 0);
+            pb[j] += BK;
+        }
+    };
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: row * 128 bytes + ((2 s + lh) ^ swz(row)) * 16
+    int offA[4], offB[2], swA[4], swB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int row = wm * 128 + i * 32 + lr; offA[i] = row * 128; swA[i] = (row >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offB[j] = BM * BK * 2 + row * 128; swB[j] = (row >> 1) & 7; }
+
+    const int KT = p.K / BK;
+    issue(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
+        if (kt + 1 < KT) issue((kt + 1) & 1);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            s16x8_t af[4], bf_[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const s16x8_t*>(st + offA[i] + (((2 * s + lh) ^ swA[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf_[j] = *reinterpret_cast<const s16x8_t*>(st + offB[j] + (((2 * s + lh) ^ swB[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bf_[j]), acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // this wave's DMA of the next stage has landed
+        __syncthreads();                                   // everyone's has, and everyone is done reading this stage
+    }
+
+    // ---- epilogue: one 32 x 64 fp32 slab per wave at a time through LDS, 16-byte stores along n
+    float* slab = reinterpret_cast<float*>(smem) + wave * 32 * SLAB_W;
+    const bf16* R = reinterpret_cast<const bf16*>(p.R);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gn = n0 + wn * 64 + j * 32 + lr;
+            const float bv = (p.bias_mode == 1 && gn < p.N) ? p.bias[gn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLAB_W + j * 32 + lr] = acc[i][j][r] * p.alpha + bv;
+        }
+        // (wave-private slab: LDS operations of one wave stay in order, no barrier)
+        const int gm0 = m0 + wm * 128 + i * 32, gn0 = n0 + wn * 64;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = lane + it * 64, row = idx >> 3, ch = idx & 7;          // 8 chunks of 8 outputs per row
+            const int gm = gm0 + row, gn = gn0 + ch * 8;
+            if (gm >= p.M || gn >= p.N) continue;
+            float v[8];
+            const float4 s0 = *reinterpret_cast<const float4*>(slab + row * SLAB_W + ch * 8);
+            const float4 s1 = *reinterpret_cast<const float4*>(slab + row * SLAB_W + ch * 8 + 4);
+            v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
+            if (R) {
+                const Vec16<bf16> rv = ld16<bf16>(R + (int64_t)gm * p.r_ms + gn);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv.get(e);
+            }
+            if (p.out_f32) {
+                float* dst = reinterpret_cast<float*>(p.C) + (int64_t)gm * p.c_ms + gn;
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                Vec16<bf16> ov;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) ov.set2(e, v[e], v[e + 1]);
+                st16<bf16>(reinterpret_cast<bf16*>(p.C) + (int64_t)gm * p.c_ms + gn, ov);
+            }
+        }
+    }
+}
+
+bool gemm256_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("DTT_GEMM256"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+
+}  // namespace
+
+// 1: not covered (the caller goes on to the general kernels); 0 / negative as dtt_gemm
+int dtt_gemm256_try(const DttGemm& p, hipStream_t st) {
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!gemm256_enabled() || p.dtype != 1 || p.a_mode || p.b_mode || p.batch != 1 || p.splitk != 1 || p.atomic || p.act ||
+        p.a_ks != 1 || p.b_ks != 1 || p.c_ns != 1 || p.K % BK || p.a_ms % 8 || p.b_ns % 8 || p.N % 8 || p.c_ms % 8 ||
+        p.bias_mode > 1 || (p.R && (p.r_ns != 1 || p.r_ms % 8 || !al(p.R))) || !al(p.A) || !al(p.B) || !al(p.C))
+        return 1;
+    const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (p.M < 192 || p.N < 192 || tiles < 192) return 1;   // fewer tiles than CUs: the 128 x 128 form fills the chip better
+    static bool attr = false;
+    const int sm = 2 * STAGE_BYTES;
+    if (!attr) { hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sm); attr = true; }
+    hipLaunchKernelGGL(gemm256_kernel, dim3((unsigned)tiles), dim3(512), sm, st, p);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}

@@ -15,6 +15,8 @@
 //     of row r is stored at piece c ^ ((r >> 1) & 7) -- the lane's SOURCE address carries the swizzle -- which makes
 //     the fragment reads (16 rows x one piece per lane group) conflict-free.
 // Epilogue: bias[n], residual, bf16 or fp32 store, through an LDS slab per wave (16-byte stores along n).
+#include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "../../include/dtt_hip.h"
 
@@ -27,6 +29,12 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;            // 64 KB
 constexpr int SLAB_W = 64 + 4;                             // epilogue slab row (floats)
 
+// RC: both operands contiguous along their rows, k-major (A(m,k) = A[k * a_ks + m], B(k,n) = B[k * b_ks + n]): the
+// weight-gradient products dW = dG^T [h_{t-1} | x] of the LSTMs (K = rows of the step, split over grid.y, fp32
+// atomic accumulation).  LDS image [64 k][256 rows], 16-byte piece c of k-row r stored at c ^ ((r & 3) << 2): the
+// four k-rows one transposing read (ds_read_b64_tr_b16) touches fall into four different 16-bank slots.
+// SHIFT (B only): the LSTM row shift, k -> k + sh_shift, zero where (k / sh_heads) % sh_L == sh_edge.
+template <bool RC>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const DttGemm p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
@@ -40,27 +48,48 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const DttGemm p) {
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    const int KT = p.K / BK, per_split = (KT + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kt0 = blockIdx.y * per_split, kt1 = min(KT, kt0 + per_split);
+    if (kt0 >= kt1) return;
 
-    // ---- DMA sources: wave-instruction j of this wave fills rows (wave * 4 + j) * 8 .. + 8 of a 256-row image
+    // ---- DMA sources.  KC: wave-instruction j fills rows (wave * 4 + j) * 8 .. + 8 of a 256-row image;
+    //      RC: k-rows (wave * 4 + j) * 2, + 1 of a 64-k-row image
     const bf16* pa[4];
     const bf16* pb[4];
+    int kb[4];                                             // RC + shift: k-row of the lane's piece inside the tile
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int L = (wave * 4 + j) * 64 + lane, row = L >> 3, pos = L & 7, piece = pos ^ ((row >> 1) & 7);
-        pa[j] = A + (int64_t)min(m0 + row, p.M - 1) * p.a_ms + piece * 8;
-        pb[j] = B + (int64_t)min(n0 + row, p.N - 1) * p.b_ns + piece * 8;
+        const int L = (wave * 4 + j) * 64 + lane;
+        if constexpr (!RC) {
+            const int row = L >> 3, pos = L & 7, piece = pos ^ ((row >> 1) & 7);
+            pa[j] = A + (int64_t)min(m0 + row, p.M - 1) * p.a_ms + (int64_t)kt0 * BK + piece * 8;
+            pb[j] = B + (int64_t)min(n0 + row, p.N - 1) * p.b_ns + (int64_t)kt0 * BK + piece * 8;
+        } else {
+            const int krow = L >> 5, pos = L & 31, piece = pos ^ ((krow & 3) << 2);
+            kb[j] = krow;
+            pa[j] = A + (int64_t)(kt0 * BK + krow) * p.a_ks + min(m0 + piece * 8, p.M - 8);
+            pb[j] = B + (int64_t)(kt0 * BK + krow + (p.b_mode == 2 ? p.sh_shift : 0)) * p.b_ks + min(n0 + piece * 8, p.N - 8);
+        }
     }
-    auto issue = [&](int stage) {
+    const int64_t stepA = RC ? (int64_t)BK * p.a_ks : BK, stepB = RC ? (int64_t)BK * p.b_ks : BK;
+    auto issue = [&](int stage, int kt) {
         unsigned char* sa = smem + stage * STAGE_BYTES + (wave * 4) * 1024;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             __builtin_amdgcn_global_load_lds((gptr_t)pa[j], (lptr_t)(sa + j * 1024), 16, 0, 0);
-            pa[j] += BK;
+            pa[j] += stepA;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)pb[j], (lptr_t)(sa + BM * BK * 2 + j * 1024), 16, 0, 0);
-            pb[j] += BK;
+            const bf16* src = pb[j];
+            if constexpr (RC) {
+                if (p.b_mode == 2) {
+                    const int gk = kt * BK + kb[j];
+                    if ((gk / p.sh_heads) % p.sh_L == p.sh_edge) src = reinterpret_cast<const bf16*>(&dtt_zero16);
+                }
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + BM * BK * 2 + j * 1024), 16, 0, 0);
+            pb[j] += stepB;
         }
     };
 
@@ -72,27 +101,54 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const DttGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment addresses: row * 128 bytes + ((2 s + lh) ^ swz(row)) * 16
+    // fragment addresses.  KC: row * 128 bytes + ((2 s + lh) ^ swz(row)) * 16.
+    // RC (transposing read, see tr_frag): k-row 16 s + 8 lh + q, columns base + 16 g + 4 p .. + 3
     int offA[4], offB[2], swA[4], swB[2];
+    if constexpr (!RC) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int row = wm * 128 + i * 32 + lr; offA[i] = row * 128; swA[i] = (row >> 1) & 7; }
+        for (int i = 0; i < 4; ++i) { const int row = wm * 128 + i * 32 + lr; offA[i] = row * 128; swA[i] = (row >> 1) & 7; }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offB[j] = BM * BK * 2 + row * 128; swB[j] = (row >> 1) & 7; }
+        for (int j = 0; j < 2; ++j) { const int row = wn * 64 + j * 32 + lr; offB[j] = BM * BK * 2 + row * 128; swB[j] = (row >> 1) & 7; }
+    } else {
+        const int g = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = wm * 128 + i * 32 + 16 * g + 4 * pp;
+            offA[i] = (8 * lh + q) * 512 + (((col >> 3) ^ (q << 2)) << 4) + (col & 7) * 2; swA[i] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 64 + j * 32 + 16 * g + 4 * pp;
+            offB[j] = BM * BK * 2 + (8 * lh + q) * 512 + (((col >> 3) ^ (q << 2)) << 4) + (col & 7) * 2; swB[j] = 0;
+        }
+    }
 
-    const int KT = p.K / BK;
-    issue(0);
+    issue(0, kt0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
-        if (kt + 1 < KT) issue((kt + 1) & 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const unsigned char* st = smem + ((kt - kt0) & 1) * STAGE_BYTES;
+        if (kt + 1 < kt1) issue((kt - kt0 + 1) & 1, kt + 1);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             s16x8_t af[4], bf_[2];
+            if constexpr (!RC) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const s16x8_t*>(st + offA[i] + (((2 * s + lh) ^ swA[i]) << 4));
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const s16x8_t*>(st + offA[i] + (((2 * s + lh) ^ swA[i]) << 4));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf_[j] = *reinterpret_cast<const s16x8_t*>(st + offB[j] + (((2 * s + lh) ^ swB[j]) << 4));
+                for (int j = 0; j < 2; ++j) bf_[j] = *reinterpret_cast<const s16x8_t*>(st + offB[j] + (((2 * s + lh) ^ swB[j]) << 4));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16* r0 = reinterpret_cast<const bf16*>(st + offA[i] + s * 16 * 512);
+                    af[i] = tr_frag(r0, r0 + 4 * 256);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16* r0 = reinterpret_cast<const bf16*>(st + offB[j] + s * 16 * 512);
+                    bf_[j] = tr_frag(r0, r0 + 4 * 256);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -103,6 +159,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const DttGemm p) {
         __syncthreads();                                   // everyone's has, and everyone is done reading this stage
     }
 
+    if (p.atomic) {
+        // split-K partial sums: one register of a 32x32 accumulator is 32 consecutive n in two rows
+        float* Cf = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int gn = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (gm < p.M && gn < p.N) atomicAdd(Cf + (int64_t)gm * p.c_ms + gn, acc[i][j][r] * p.alpha);
+                }
+            }
+        return;
+    }
     // ---- epilogue: one 32 x 64 fp32 slab per wave at a time through LDS, 16-byte stores along n
     float* slab = reinterpret_cast<float*>(smem) + wave * 32 * SLAB_W;
     const bf16* R = reinterpret_cast<const bf16*>(p.R);
@@ -157,16 +229,35 @@ bool gemm256_enabled() {
 // 1: not covered (the caller goes on to the general kernels); 0 / negative as dtt_gemm
 int dtt_gemm256_try(const DttGemm& p, hipStream_t st) {
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (!gemm256_enabled() || p.dtype != 1 || p.a_mode || p.b_mode || p.batch != 1 || p.splitk != 1 || p.atomic || p.act ||
-        p.a_ks != 1 || p.b_ks != 1 || p.c_ns != 1 || p.K % BK || p.a_ms % 8 || p.b_ns % 8 || p.N % 8 || p.c_ms % 8 ||
-        p.bias_mode > 1 || (p.R && (p.r_ns != 1 || p.r_ms % 8 || !al(p.R))) || !al(p.A) || !al(p.B) || !al(p.C))
+    if (!gemm256_enabled() || p.dtype != 1 || p.a_mode || p.batch != 1 || p.act || p.c_ns != 1 || p.K % BK ||
+        !al(p.A) || !al(p.B) || !al(p.C) || p.M < 192 || p.N < 192)
         return 1;
     const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    if (p.M < 192 || p.N < 192 || tiles < 192) return 1;   // fewer tiles than CUs: the 128 x 128 form fills the chip better
-    static bool attr = false;
     const int sm = 2 * STAGE_BYTES;
-    if (!attr) { hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sm); attr = true; }
-    hipLaunchKernelGGL(gemm256_kernel, dim3((unsigned)tiles), dim3(512), sm, st, p);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        hipFuncSetAttribute((const void*)gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        attr = true;
+    }
+    const bool kc = p.a_ks == 1 && p.b_ks == 1 && p.b_mode == 0;
+    const bool rc = p.a_ms == 1 && p.b_ns == 1 && (p.b_mode == 0 || p.b_mode == 2);
+    if (kc) {
+        // plain store, k-contiguous operands
+        if (p.splitk != 1 || p.atomic || p.a_ms % 8 || p.b_ns % 8 || p.N % 8 || p.c_ms % 8 || p.bias_mode > 1 ||
+            (p.R && (p.r_ns != 1 || p.r_ms % 8 || !al(p.R))) || tiles < 192)
+            return 1;                                      // fewer tiles than CUs: the 128 x 128 form fills the chip better
+        hipLaunchKernelGGL(gemm256_kernel<false>, dim3((unsigned)tiles), dim3(512), sm, st, p);
+    } else if (rc) {
+        // split-K weight gradients, row-contiguous operands
+        if (!p.atomic || !p.out_f32 || p.bias_mode || p.R || p.a_ks % 8 || p.b_ks % 8 || p.M % 8 || p.N % 8 ||
+            p.K / BK < 64 || p.N < 512)             // (one column of tiles: the split-K atomics outweigh the mainloop)
+            return 1;
+        int sk = (int)std::max<int64_t>(1, std::min<int64_t>(p.K / BK / 8, (256 + tiles - 1) / tiles));
+        hipLaunchKernelGGL(gemm256_kernel<true>, dim3((unsigned)tiles, sk), dim3(512), sm, st, p);
+    } else {
+        return 1;
+    }
     DTT_LAUNCH_CHECK();
     return 0;
 }

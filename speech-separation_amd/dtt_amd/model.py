@@ -158,6 +158,11 @@ class IDPModule(nn.Module):
         ch = int(in_channels // n_heads)
         if ch % 16 != 0 and ch > 16:
             raise DttError("channels per head must be a multiple of 16 (GroupNorm groups)")
+        H = 2 * ch                                          # hidden width of the BiLSTMs (latent.py:87-92)
+        if not (H % 32 == 0 and (32 <= H <= 256 or H in (512, 1024))):
+            raise DttError(f"IDPModule: in_channels / n_heads = {ch} gives LSTM hidden width {H}; the recurrent kernels "
+                           "cover H = 32, 64, ..., 256, 512 and 1024 (channels per head 16 ... 128 in steps of 16, "
+                           "256 or 512)")
         self.tc_rnn = TC_FC_RNN(n_heads, ch)
         self.fc_rnn = TC_FC_RNN(n_heads, ch)
 

@@ -280,3 +280,51 @@ def test_pack_conv3_dgrad_is_the_rotated_transpose(dt, Co, Ci):
     ref = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, 9 * Co).to(dt)
     assert got.shape == ref.shape and got.dtype == dt
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("M,N,K,res,f32", [(2050, 3072, 128, True, False), (4100, 3000, 64, False, True),
+                                          (33280, 4096, 256, False, False)])
+def test_gemm256_k_contiguous(M, N, K, res, f32):
+    """The 256 x 256 x 64 LDS-DMA kernel (gemm256.hip) takes the large k-contiguous bf16 products (>= 192 tiles):
+    ragged edges in both dimensions, bias, residual, bf16 and fp32 stores, against fp32 math on the same bf16
+    inputs; and the same call with the kernel switched off must agree to bf16 rounding."""
+    from dtt_amd._lib import gemm_raw
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    w = torch.randn(N, K, device=dev, generator=g).bfloat16()
+    b = torch.randn(N, device=dev, generator=g)
+    r = torch.randn(M, N, device=dev, generator=g).bfloat16() if res else None
+    c = torch.full((M, N), float("nan"), device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    kw = dict(A=a, B=w, C=c, bias=b, M=M, N=N, K=K, a_ms=K, a_ks=1, b_ks=1, b_ns=K, c_ms=N, c_ns=1, dtype=1,
+              bias_mode=1, out_f32=1 if f32 else 0)
+    if res:
+        kw.update(R=r, r_ms=N, r_ns=1)
+    gemm_raw(**kw)
+    ref = a.float() @ w.float().t() + b
+    if res:
+        ref = ref + r.float()
+    assert rel_err(c, ref) < (1e-5 if f32 else 1e-2)
+    assert float((c.float() - ref).abs().max() / ref.abs().max()) < (1e-5 if f32 else 1e-2)
+
+
+@pytest.mark.parametrize("R,H,L", [(33280, 512, 16), (8320, 512, 65)])
+def test_gemm256_weight_gradient_with_row_shift(R, H, L):
+    """Row-contiguous split-K form of gemm256.hip: dW_hh = dG^T h_{t-1} with the LSTM row shift (zero rows at the
+    sequence edge), fp32 atomic accumulation, against fp32 math."""
+    from dtt_amd._lib import gemm_raw
+    dev = "cuda"
+    G4 = 4 * H
+    g = torch.Generator(device=dev).manual_seed(R + H)
+    dG = torch.randn(R, 2, G4, device=dev, generator=g).bfloat16()
+    y = torch.randn(R, 2 * H, device=dev, generator=g).bfloat16()
+    k = torch.arange(R, device=dev)
+    for di, (shift, edge) in enumerate(((-2, 0), (2, L - 1))):
+        out = torch.zeros(G4, H, device=dev)
+        gemm_raw(A=dG[:, di], B=y[:, di * H:], C=out, M=G4, N=H, K=R, splitk=8, a_ms=1, a_ks=2 * G4, b_ks=2 * H, b_ns=1,
+                 c_ms=H, c_ns=1, dtype=1, atomic=1, out_f32=1, b_mode=2, sh_shift=shift, sh_heads=2, sh_L=L, sh_edge=edge)
+        keep = (k // 2) % L != edge
+        ys = torch.zeros(R, H, device=dev)
+        ys[keep] = y[(k + shift).clamp(0, R - 1)[keep], di * H:(di + 1) * H].float()
+        ref = dG[:, di].float().t() @ ys
+        assert rel_err(out, ref) < 1e-4

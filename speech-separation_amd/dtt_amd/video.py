@@ -1,8 +1,8 @@
-"""Lip-ROI video encoders.  On the AV forward/backward path but outside the
-hand-written-kernel scope of this round:
-stock PyTorch-ROCm modules (MIOpen convolutions), same parameter names as the
-reference, and NO network fetch (the reference downloads a checkpoint with gdown
-in __init__, resnet_video_encoder.py:46-60).
+"""Lip-ROI video encoders.  Same parameter names as the
+reference and NO network fetch (the reference downloads a checkpoint with gdown in __init__,
+resnet_video_encoder.py:46-60).  ResNet-18 encoder: BatchNorm + Swish (+ residual), the max pool and the stride-1
+3x3 convolutions of the trunk run on the HIP kernels (ops.BatchNormAct, ops.MaxPool3x3s2, ops.Conv3x3); the front-end
+convolution, the three stride-2 3x3 and the three 1x1 convolutions are MIOpen's.  ShuffleNetV2 encoder: stock modules.
 
 Reference: src/model/VideoEncoders/{resnet,resnet_video_encoder}.py.
 """
@@ -17,6 +17,18 @@ from torch import nn
 
 _NATIVE_BN = os.environ.get("DTT_VIDEO_NATIVE_BN", "1") == "1"
 _FUSED_BN = os.environ.get("DTT_VIDEO_FUSED_BN", "1") == "1"      # 0: ATen BatchNorm + elementwise Swish (A/B switch)
+_OWN_CONV = os.environ.get("DTT_VIDEO_OWN_CONV", "1") == "1"      # 0: every trunk convolution on MIOpen (A/B switch)
+
+
+def _conv3x3(conv, x):
+    """The trunk's stride-1 3x3 convolutions on the HIP kernels (ops.Conv3x3); stride-2 and 1x1 ones on MIOpen."""
+    if (_OWN_CONV and conv.stride == (1, 1) and conv.kernel_size == (3, 3) and conv.in_channels % 32 == 0
+            and conv.out_channels % 32 == 0 and x.dtype in (torch.bfloat16, torch.float32)):
+        from .ops import Conv3x3
+        if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
+            x = x.to(torch.get_autocast_dtype("cuda"))
+        return Conv3x3.apply(x, conv.weight)
+    return conv(x)
 
 
 class _NativeBN:
@@ -63,12 +75,12 @@ class BasicBlock(nn.Module):
             y = self.relu1(self.bn1(self.conv1(x)))
             y = self.bn2(self.conv2(y))
             return self.relu2(y + r)
-        # BatchNorm + Swish (+ residual) as ONE HIP pass forward and two backward (ops.BatchNormAct): the
-        # convolutions stay MIOpen's, everything between them is ours
+        # BatchNorm + Swish (+ residual) as ONE HIP pass forward and two backward (ops.BatchNormAct); the stride-1
+        # 3x3 convolutions on our kernels, the stride-2 / 1x1 ones on MIOpen
         from .ops import batch_norm_act
         r = x if self.downsample is None else batch_norm_act(self.downsample[0](x), self.downsample[1], 0)
-        y = batch_norm_act(self.conv1(x), self.bn1, 1)
-        return batch_norm_act(self.conv2(y), self.bn2, 1, res=r)
+        y = batch_norm_act(_conv3x3(self.conv1, x), self.bn1, 1)
+        return batch_norm_act(_conv3x3(self.conv2, y), self.bn2, 1, res=r)
 
 
 class ResNet18Trunk(nn.Module):

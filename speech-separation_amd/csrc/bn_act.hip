@@ -131,17 +131,18 @@ __global__ __launch_bounds__(NT) void bn_stats_partial(const T* __restrict__ x, 
     for (int c = tid; c < C; c += NT) dst[c * 2 + 1] = chv[c];
 }
 
-// pass 2: Chan merge of the chunk partials, 8 lane groups per channel each walking every eighth chunk, then a
-// fixed-order merge of the 8 (a single serial walk over ~500 chunks per channel cost 270 us per BatchNorm);
-// stats[c] = {mean, rstd}
-__global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ partial, float* __restrict__ stats, int P,
+// pass 2: Chan merge of the chunk partials, FG lane groups per channel each walking every FG-th chunk, then a
+// fixed-order merge of the FG (a single serial walk over ~500 chunks per channel cost 270 us per BatchNorm, 8
+// groups 21 us, 32 groups of a 1024-thread workgroup ~8); stats[c] = {mean, rstd}
+constexpr int FG = 32;
+__global__ __launch_bounds__(32 * FG) void bn_stats_finalize(const float* __restrict__ partial, float* __restrict__ stats, int P,
                                                          int C, int chunk, int nchunks, float eps) {
-    __shared__ float sh[3][8][33];
+    __shared__ float sh[3][FG][33];
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     if (c < C)
-        for (int k = g; k < nchunks; k += 8) {
+        for (int k = g; k < nchunks; k += FG) {
             const float2 s = *reinterpret_cast<const float2*>(partial + ((int64_t)k * C + c) * 2);
             const float nb = (float)(min(P, (k + 1) * chunk) - k * chunk);
             const float d = s.x - mean, nn = n + nb;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
     if (g == 0 && c < C) {
         float tn = 0.f, tm = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < FG; ++i) {
             const float nb = sh[0][i][cl];
             if (nb > 0.f) {
                 const float d = sh[1][i][cl] - tm, nn = tn + nb;
@@ -219,14 +220,14 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_partial(const T* __restrict__ x
 }
 
 // sums[c] = {sum da, sum da * xhat} over all chunks (fixed order); dgb[c] = {dgamma, dbeta}
-__global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__ partial, float* __restrict__ sums,
-                                                       float* __restrict__ dgb, int C, int nchunks) {
-    __shared__ float sh[2][8][33];
+__global__ __launch_bounds__(32 * FG) void bn_bwd_finalize(const float* __restrict__ partial, float* __restrict__ sums,
+                                                          float* __restrict__ dgb, int C, int nchunks) {
+    __shared__ float sh[2][FG][33];
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float a = 0.f, q = 0.f;
     if (c < C)
-        for (int k = g; k < nchunks; k += 8) {
+        for (int k = g; k < nchunks; k += FG) {
             const float2 s = *reinterpret_cast<const float2*>(partial + ((int64_t)k * C + c) * 2);
             a += s.x; q += s.y;
         }
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__
     if (g == 0 && c < C) {
         float ta = 0.f, tq = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { ta += sh[0][i][cl]; tq += sh[1][i][cl]; }
+        for (int i = 0; i < FG; ++i) { ta += sh[0][i][cl]; tq += sh[1][i][cl]; }
         sums[c * 2] = ta; sums[c * 2 + 1] = tq;
         dgb[c * 2] = tq; dgb[c * 2 + 1] = ta;
     }
@@ -435,7 +436,7 @@ extern "C" int dtt_bn_stats(const void* x, float* partial, float* stats, int P, 
     const size_t sm = (size_t)(NT * ept + C) * sizeof(float);
     if (dtype) hipLaunchKernelGGL(bn_stats_partial<bf16>, dim3(nch), dim3(NT), sm, ST, (const bf16*)x, partial, P, C, chunk);
     else hipLaunchKernelGGL(bn_stats_partial<float>, dim3(nch), dim3(NT), sm, ST, (const float*)x, partial, P, C, chunk);
-    hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 31) / 32), dim3(256), 0, ST, partial, stats, P, C, chunk, nch, eps);
+    hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 31) / 32), dim3(32 * FG), 0, ST, partial, stats, P, C, chunk, nch, eps);
     DTT_LAUNCH_CHECK();
     return 0;
 }
@@ -467,7 +468,7 @@ extern "C" int dtt_bn_act_bwd(const void* x, const void* res, const void* dz, co
     if (dtype) { if (act == 1) BP(bf16, 1); else if (act == 2) BP(bf16, 2); else BP(bf16, 0); }
     else { if (act == 1) BP(float, 1); else if (act == 2) BP(float, 2); else BP(float, 0); }
 #undef BP
-    hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, ST, partial, sums, dgb, C, nch);
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 31) / 32), dim3(32 * FG), 0, ST, partial, sums, dgb, C, nch);
 #define BA(TT, A) hipLaunchKernelGGL((bn_act_bwd_apply<TT, A>), dim3(nch), dim3(NT), 0, ST, (const TT*)x, (const TT*)res, (const TT*)dz, stats, gamma, beta, sums, (TT*)dx, (TT*)dres, P, C, chunk, training)
     if (dtype) { if (act == 1) BA(bf16, 1); else if (act == 2) BA(bf16, 2); else BA(bf16, 0); }
     else { if (act == 1) BA(float, 1); else if (act == 2) BA(float, 2); else BA(float, 0); }

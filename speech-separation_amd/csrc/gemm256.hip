@@ -29,6 +29,40 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;            // 64 KB
 constexpr int SLAB_W = 64 + 4;                             // epilogue slab row (floats)
 
+// ds_read_b64_tr_b16 through inline asm: hipcc's wait-count pass makes every LDS read issued through the builtin
+// wait for ALL outstanding LDS-DMA (`s_waitcnt vmcnt(0)` in front of the first fragment read of a k-step: the DMA of
+// the next stage, issued just before, never overlapped the MFMAs).  The asm form is opaque to that pass.  One
+// statement reads the 12 half-fragments of a k-substep (4 A + 2 B fragments, k-rows q and q + 4 each); rc_fence<N>
+// waits until at most N younger LDS reads are outstanding (LDS returns in order) and only then hands the registers
+// to the compiler (the "+v" operands: nothing may read or copy them before the wait).
+struct RcFrag { s16x4_t lo[6], hi[6]; };
+template <int OFF>
+__device__ __forceinline__ void rc_read(RcFrag& f, const unsigned (&a)[6]) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %12 offset:%18\n\tds_read_b64_tr_b16 %1, %12 offset:%19\n\t"
+        "ds_read_b64_tr_b16 %2, %13 offset:%18\n\tds_read_b64_tr_b16 %3, %13 offset:%19\n\t"
+        "ds_read_b64_tr_b16 %4, %14 offset:%18\n\tds_read_b64_tr_b16 %5, %14 offset:%19\n\t"
+        "ds_read_b64_tr_b16 %6, %15 offset:%18\n\tds_read_b64_tr_b16 %7, %15 offset:%19\n\t"
+        "ds_read_b64_tr_b16 %8, %16 offset:%18\n\tds_read_b64_tr_b16 %9, %16 offset:%19\n\t"
+        "ds_read_b64_tr_b16 %10, %17 offset:%18\n\tds_read_b64_tr_b16 %11, %17 offset:%19"
+        : "=&v"(f.lo[0]), "=&v"(f.hi[0]), "=&v"(f.lo[1]), "=&v"(f.hi[1]), "=&v"(f.lo[2]), "=&v"(f.hi[2]),
+          "=&v"(f.lo[3]), "=&v"(f.hi[3]), "=&v"(f.lo[4]), "=&v"(f.hi[4]), "=&v"(f.lo[5]), "=&v"(f.hi[5])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "n"(OFF), "n"(OFF + 2048));
+}
+template <int N>
+__device__ __forceinline__ void rc_fence(RcFrag& f) {
+    asm volatile("s_waitcnt lgkmcnt(%12)"
+                 : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2]),
+                   "+v"(f.lo[3]), "+v"(f.hi[3]), "+v"(f.lo[4]), "+v"(f.hi[4]), "+v"(f.lo[5]), "+v"(f.hi[5])
+                 : "n"(N));
+}
+__device__ __forceinline__ bf16x8_t rc_join(const s16x4_t& lo, const s16x4_t& hi) {
+    s16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // RC: both operands contiguous along their rows, k-major (A(m,k) = A[k * a_ks + m], B(k,n) = B[k * b_ks + n]): the
 // weight-gradient products dW = dG^T [h_{t-1} | x] of the LSTMs (K = rows of the step, split over grid.y, fp32
 // atomic accumulation).  LDS image [64 k][256 rows], 16-byte piece c of k-row r stored at c ^ ((r & 3) << 2): the
@@ -40,8 +74,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const DttGemm p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;
     const int tiles_n = (p.N + BN - 1) / BN, ntile = gridDim.x;
-    int tile = blockIdx.x;
-    {   // XCD-aware order: consecutive logical tiles (which share an A panel) run on one XCD
+    int tile = blockIdx.x, ks = blockIdx.y;
+    if (RC && gridDim.y % 8 == 0 && p.cphase == 0) {
+        // split-K: an XCD (linear workgroup id % 8) takes whole k-splits, every output tile of them -- the 16 tiles of
+        // a k-split read the same K / splitk rows of A and B, so each operand byte crosses the fabric once and is
+        // shared through that XCD's L2 (tiles of one A panel per XCD: every XCD streams all of K for its panel,
+        // 2.4x the traffic at 2048 x 512 x 33 280)
+        const int lin = blockIdx.y * ntile + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+        ks = xcd * ((int)gridDim.y >> 3) + slot / ntile;
+        tile = slot % ntile;
+    } else {   // XCD-aware order: consecutive logical tiles (which share an A panel) run on one XCD
         const int per = ntile / 8;
         if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
     }
@@ -49,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const DttGemm p) {
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* B = reinterpret_cast<const bf16*>(p.B);
     const int KT = p.K / BK, per_split = (KT + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int kt0 = blockIdx.y * per_split, kt1 = min(KT, kt0 + per_split);
+    const int kt0 = ks * per_split, kt1 = min(KT, kt0 + per_split);
     if (kt0 >= kt1) return;
 
     // ---- DMA sources.  KC: wave-instruction j fills rows (wave * 4 + j) * 8 .. + 8 of a 256-row image;
@@ -126,29 +168,46 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const DttGemm p) {
     issue(0, kt0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
     __syncthreads();
+    if constexpr (RC) {
+        const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const unsigned sb = lds0 + ((kt - kt0) & 1) * STAGE_BYTES;
+            if (kt + 1 < kt1) issue((kt - kt0 + 1) & 1, kt + 1);
+            unsigned ad[6];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ad[i] = sb + offA[i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ad[4 + j] = sb + offB[j];
+            RcFrag f0, f1;
+#define RC_MMA(F) do { _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rc_join(F.lo[i], F.hi[i]), rc_join(F.lo[4 + j], F.hi[4 + j]), acc[i][j], 0, 0, 0); } while (0)
+            rc_read<0>(f0, ad);
+            rc_read<8192>(f1, ad);
+            rc_fence<12>(f0);
+            RC_MMA(f0);
+            rc_read<16384>(f0, ad);
+            rc_fence<12>(f1);
+            RC_MMA(f1);
+            rc_read<24576>(f1, ad);
+            rc_fence<12>(f0);
+            RC_MMA(f0);
+            rc_fence<0>(f1);
+            RC_MMA(f1);
+#undef RC_MMA
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // this wave's DMA of the next stage has landed
+            __syncthreads();                               // everyone's has, and everyone is done reading this stage
+        }
+    } else {
     for (int kt = kt0; kt < kt1; ++kt) {
         const unsigned char* st = smem + ((kt - kt0) & 1) * STAGE_BYTES;
         if (kt + 1 < kt1) issue((kt - kt0 + 1) & 1, kt + 1);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             s16x8_t af[4], bf_[2];
-            if constexpr (!RC) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const s16x8_t*>(st + offA[i] + (((2 * s + lh) ^ swA[i]) << 4));
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const s16x8_t*>(st + offA[i] + (((2 * s + lh) ^ swA[i]) << 4));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf_[j] = *reinterpret_cast<const s16x8_t*>(st + offB[j] + (((2 * s + lh) ^ swB[j]) << 4));
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bf16* r0 = reinterpret_cast<const bf16*>(st + offA[i] + s * 16 * 512);
-                    af[i] = tr_frag(r0, r0 + 4 * 256);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bf16* r0 = reinterpret_cast<const bf16*>(st + offB[j] + s * 16 * 512);
-                    bf_[j] = tr_frag(r0, r0 + 4 * 256);
-                }
-            }
+            for (int j = 0; j < 2; ++j) bf_[j] = *reinterpret_cast<const s16x8_t*>(st + offB[j] + (((2 * s + lh) ^ swB[j]) << 4));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -158,8 +217,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const DttGemm p) {
         __builtin_amdgcn_s_waitcnt(0x0F70);                // this wave's DMA of the next stage has landed
         __syncthreads();                                   // everyone's has, and everyone is done reading this stage
     }
+    }
 
     if (p.atomic) {
+        if (p.cphase & 2) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.C)[0] = 1.f; return; }
         // split-K partial sums: one register of a 32x32 accumulator is 32 consecutive n in two rows
         float* Cf = reinterpret_cast<float*>(p.C);
 #pragma unroll
@@ -251,10 +312,11 @@ int dtt_gemm256_try(const DttGemm& p, hipStream_t st) {
     } else if (rc) {
         // split-K weight gradients, row-contiguous operands
         if (!p.atomic || !p.out_f32 || p.bias_mode || p.R || p.a_ks % 8 || p.b_ks % 8 || p.M % 8 || p.N % 8 ||
-            p.K / BK < 64 || p.N < 512)             // (one column of tiles: the split-K atomics outweigh the mainloop)
+            p.K / BK < 64 || p.N < (getenv("DTT_NMIN") ? atoi(getenv("DTT_NMIN")) : 512))             // (one column of tiles: the split-K atomics outweigh the mainloop)
             return 1;
         int sk = (int)std::max<int64_t>(1, std::min<int64_t>(p.K / BK / 8, (256 + tiles - 1) / tiles));
-        hipLaunchKernelGGL(gemm256_kernel<true>, dim3((unsigned)tiles, sk), dim3(512), sm, st, p);
+        { DttGemm q = p; if (getenv("DTT_MAP0")) q.cphase = 1; if (getenv("DTT_NOEPI")) q.cphase |= 2; if (getenv("DTT_SK")) sk = atoi(getenv("DTT_SK"));
+        hipLaunchKernelGGL(gemm256_kernel<true>, dim3((unsigned)tiles, sk), dim3(512), sm, st, q); }
     } else {
         return 1;
     }

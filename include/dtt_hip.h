@@ -66,8 +66,16 @@ typedef struct DttGemm {
      * [B][cFo][cTo] output (c_ms = row stride of that tensor)                                  */
     int32_t cphase;
     int32_t reserved_;
+    /* optional scratch for split-K (atomic = 1) products: with ws_bytes >= dtt_gemm_ws_bytes(p) the k-splits store
+     * their partial tiles there (plain 16-byte stores) and a second launch adds their sum to C, instead of
+     * splitk * M * N fp32 atomics (48 of the 123 us of a 2048 x 512 x 33 280 LSTM weight gradient).  NULL / too
+     * small: atomics.  Contents are undefined afterwards; calls sharing one workspace must be stream-ordered.   */
+    void* ws;
+    int64_t ws_bytes;
 } DttGemm;
 int dtt_gemm(const DttGemm* p, void* stream);
+/* bytes of workspace with which dtt_gemm(p) would take the store-and-sum split-K path; 0: it has no use for one */
+int64_t dtt_gemm_ws_bytes(const DttGemm* p);
 
 /* Dedicated 3x3 stride-1 'same' conv on channels-last (block_tfc_tdf.py:12-32): LDS input
  * patches shared by the nine taps; wp = [Co][9][Ci]; optional fused residual and fused

@@ -796,6 +796,9 @@ template <typename T> int dispatch(const DttGemm& p, hipStream_t st) {
 }  // namespace
 
 int dtt_gemm256_try(const DttGemm& p, hipStream_t st);   // gemm256.hip
+int64_t dtt_gemm256_ws_bytes(const DttGemm& p);
+
+extern "C" int64_t dtt_gemm_ws_bytes(const DttGemm* p) { return p ? dtt_gemm256_ws_bytes(*p) : 0; }
 
 extern "C" int dtt_gemm(const DttGemm* pp, void* stream) {
     DttGemm p = *pp;

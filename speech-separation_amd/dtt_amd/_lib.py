@@ -29,6 +29,7 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.dtt_last_error.restype = C.c_char_p
         _lib.dtt_version.restype = C.c_int
+        _lib.dtt_gemm_ws_bytes.restype = C.c_int64
     return _lib
 
 
@@ -72,6 +73,7 @@ class DttGemm(C.Structure):
         ("cFo", C.c_int32), ("cTo", C.c_int32), ("cstride", C.c_int32), ("ctrans", C.c_int32),
         ("sh_shift", C.c_int32), ("sh_heads", C.c_int32), ("sh_L", C.c_int32), ("sh_edge", C.c_int32),
         ("cphase", C.c_int32), ("reserved_", C.c_int32),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
     ]
 
 
@@ -91,4 +93,12 @@ def gemm_raw(**kw):
     kw.setdefault("alpha", 1.0)
     for k, v in kw.items():
         setattr(g, k, v)
+    if g.atomic and g.splitk > 1:
+        # split-K partial tiles through a scratch buffer instead of fp32 atomics where the kernel can use one
+        need = lib().dtt_gemm_ws_bytes(C.byref(g))
+        if need > 0:
+            import torch
+            ws = torch.empty(need, dtype=torch.uint8, device=keep[0].device)
+            keep.append(ws)
+            g.ws, g.ws_bytes = ws.data_ptr(), need
     check(lib().dtt_gemm(C.byref(g), stream_ptr()), "dtt_gemm")

@@ -87,6 +87,13 @@ int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, void* y, co
                    float* stats, int B, int F, int T, int Ci, int Co, float eps, int dtype, void* stream);
 int dtt_conv3x3_wgrad(const void* dy, const void* x, float* dw, int B, int F, int T, int Ci, int Co, int dtype,
                       void* stream);
+/* The same weight gradient (reference: autograd of the Conv2d(c, c, 3, 1, 1) of block_tfc_tdf.py:12-17) with the
+ * workgroups' partial sums stored to a caller workspace of dtt_conv3x3_wgrad_ws_bytes(...) bytes and added up by a
+ * second launch instead of fp32 atomics; dw is OVERWRITTEN (no zeroing).  _ws_bytes returns 0 for channel counts
+ * only the atomic form covers (multiples of 32 that are not multiples of 64, other than 32 -> 32). */
+int64_t dtt_conv3x3_wgrad_ws_bytes(int B, int F, int T, int Ci, int Co);
+int dtt_conv3x3_wgrad_ws(const void* dy, const void* x, float* dw, void* ws, int64_t ws_bytes, int B, int F, int T,
+                         int Ci, int Co, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * InstanceNorm2d(affine=False, eps) + exact GELU on channels-last tensors

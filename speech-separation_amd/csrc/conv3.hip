@@ -423,6 +423,7 @@ __global__ __launch_bounds__(1024) void conv_stats_finalize(const float* __restr
 struct Wg3P {
     const void* dy; const void* x; float* dw;
     int B, F, T, Ci, Co, tiles_f, tiles_t, tiles_per_wg;
+    float* ws;      // NULL: atomicAdd into dw; else partial sums as plain stores, slab [Co][9][Ci] per split (wg3_sum_kernel)
 };
 
 template <int CT>
@@ -517,16 +518,45 @@ __global__ __launch_bounds__(256, CT == 32 ? 2 : 1) void conv3x3_wgrad_kernel(Wg
         }
         __syncthreads();
     }
-    // ---- atomic accumulate: rows = co, cols = ci
+    // ---- partial sums out: rows = co, cols = ci.  Atomics into dw, or (CT == 64: one writer per element and
+    //      split) plain stores into this split's slab of the workspace
     const int lr = lane & 31;
+    float* out = p.dw;
+    const bool plain = CT == 64 && p.ws != nullptr;
+    if (plain) out = p.ws + (int64_t)blockIdx.x * p.Co * 9 * p.Ci;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int co = co0 + wm * 32 + i, ci = ci0 + wn * 32 + lr;
-            if (co < p.Co && ci < p.Ci) atomicAdd(p.dw + ((int64_t)co * 9 + tap) * p.Ci + ci, acc[tap][r]);
+            if (co < p.Co && ci < p.Ci) {
+                float* dst = out + ((int64_t)co * 9 + tap) * p.Ci + ci;
+                if (plain) *dst = acc[tap][r]; else atomicAdd(dst, acc[tap][r]);
+            }
         }
+}
+
+// dw[e] = sum over the splits' slabs (overwrites dw).  256 threads = 16 float4 columns x 16 slab groups.
+__global__ __launch_bounds__(256) void wg3_sum_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t quads,
+                                                      int nslab) {
+    __shared__ float4 sh[16][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int64_t qd = (int64_t)blockIdx.x * 16 + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qd < quads)
+        for (int s = g; s < nslab; s += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + ((int64_t)s * quads + qd) * 4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    sh[g][c] = a;
+    __syncthreads();
+    if (g == 0 && qd < quads) {
+        float4 t = sh[0][c];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) { const float4 v = sh[i][c]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(dw + qd * 4) = t;
+    }
 }
 
 // Ci = Co = 32 variant: wave w < 3 owns the column shift kw = w (taps kh = 0..2: 48 accumulator
@@ -612,7 +642,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad32_kernel(Wg3P p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-                atomicAdd(p.dw + ((int64_t)co * 9 + kh * 3 + kw) * CT + lr, acc[kh][r]);
+                if (p.ws) p.ws[(int64_t)blockIdx.x * (CT * 9 * CT) + ((int64_t)co * 9 + kh * 3 + kw) * CT + lr] = acc[kh][r];
+                else atomicAdd(p.dw + ((int64_t)co * 9 + kh * 3 + kw) * CT + lr, acc[kh][r]);
             }
     }
 }
@@ -659,38 +690,82 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
     return 0;
 }
 
+namespace {
+// split geometry of the weight-gradient kernels: ct = channel tile, nsplit = workgroups along the pixel tiles (= slabs
+// of partial sums), tpw = tiles per workgroup
+struct WgGeom { int ct, nsplit, tpw; bool c32; };
+WgGeom wg_geom(int B, int F, int T, int Ci, int Co) {
+    WgGeom g;
+    const int ntiles = B * ((F + TH - 1) / TH) * ((T + TW - 1) / TW);
+    g.c32 = Ci == 32 && Co == 32;
+    if (g.c32) {
+        g.ct = 32;
+        g.tpw = (ntiles + 767) / 768;                       // one resident wave: 3 workgroups per CU
+        g.nsplit = (ntiles + g.tpw - 1) / g.tpw;
+        return g;
+    }
+    g.ct = (Ci % 64 == 0 && Co % 64 == 0) ? 64 : 32;
+    const int combos = (Co / g.ct) * (Ci / g.ct);
+    // one resident wave of workgroups (1 per CU at CT = 64, 2 at CT = 32): each workgroup ends with 9*CT*CT/256
+    // partial sums per lane, so fewer, longer workgroups beat a finer split
+    const int target = g.ct == 64 ? 256 : 512;
+    int nsplit = max(1, min(ntiles, (target + combos - 1) / combos));
+    g.tpw = (ntiles + nsplit - 1) / nsplit;
+    g.nsplit = (ntiles + g.tpw - 1) / g.tpw;                // no empty workgroup: every slab is written in full
+    return g;
+}
+
+int wgrad_launch(const void* dy, const void* x, float* dw, float* ws, int B, int F, int T, int Ci, int Co, void* stream) {
+    const WgGeom g = wg_geom(B, F, T, Ci, Co);
+    Wg3P p{dy, x, dw, B, F, T, Ci, Co, (F + TH - 1) / TH, (T + TW - 1) / TW, g.tpw, ws};
+    if (g.c32) {
+        hipLaunchKernelGGL(conv3x3_wgrad32_kernel, dim3(g.nsplit), dim3(256), 0, ST, p);
+    } else {
+        size_t sm = (size_t)(TH * TW + PH * PW) * (g.ct + 8) * 2;
+        dim3 grid(g.nsplit, Co / g.ct, Ci / g.ct);
+        if (g.ct == 64) {
+            auto k = conv3x3_wgrad_kernel<64>;
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            hipLaunchKernelGGL(k, grid, dim3(256), sm, ST, p);
+        } else {
+            p.ws = nullptr;                                 // four waves per element: atomics
+            hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, grid, dim3(256), sm, ST, p);
+        }
+    }
+    if (p.ws) {
+        const int64_t quads = (int64_t)Co * 9 * Ci / 4;
+        hipLaunchKernelGGL(wg3_sum_kernel, dim3((unsigned)((quads + 15) / 16)), dim3(256), 0, ST, ws, dw, quads, g.nsplit);
+    }
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
 // dw [Co][9][Ci] fp32 (zeroed by the caller) += sum over pixels; bf16 only.
 extern "C" int dtt_conv3x3_wgrad(const void* dy, const void* x, float* dw, int B, int F, int T, int Ci, int Co,
                                  int dtype, void* stream) {
     DTT_CHECK(dtype == 1, "dtt_conv3x3_wgrad: bf16 only (fp32 goes through dtt_gemm)");
     DTT_CHECK(B > 0 && F > 0 && T > 0 && Ci % 32 == 0 && Co % 32 == 0, "dtt_conv3x3_wgrad: unsupported Ci=%d Co=%d", Ci, Co);
-    Wg3P p{dy, x, dw, B, F, T, Ci, Co, (F + TH - 1) / TH, (T + TW - 1) / TW, 1};
-    if (Ci == 32 && Co == 32) {
-        Wg3P q{dy, x, dw, B, F, T, Ci, Co, (F + TH - 1) / TH, (T + TW - 1) / TW, 1};
-        const int nt = B * q.tiles_f * q.tiles_t;
-        q.tiles_per_wg = (nt + 767) / 768;                  // one resident wave: 3 workgroups per CU
-        hipLaunchKernelGGL(conv3x3_wgrad32_kernel, dim3((nt + q.tiles_per_wg - 1) / q.tiles_per_wg), dim3(256), 0, ST, q);
-        DTT_LAUNCH_CHECK();
-        return 0;
-    }
-    const int ct = (Ci % 64 == 0 && Co % 64 == 0) ? 64 : 32;
-    const int ntiles = B * p.tiles_f * p.tiles_t;
-    const int combos = (Co / ct) * (Ci / ct);
-    // one resident wave of workgroups (1 per CU at CT = 64, 2 at CT = 32): each workgroup ends with
-    // 9*CT*CT/256 atomics per lane, so fewer, longer workgroups beat a finer split
-    const int target = ct == 64 ? 256 : 512;
-    int nsplit = max(1, min(ntiles, (target + combos - 1) / combos));
-    p.tiles_per_wg = (ntiles + nsplit - 1) / nsplit;
-    nsplit = (ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
-    size_t sm = (size_t)(TH * TW + PH * PW) * (ct + 8) * 2;
-    dim3 grid(nsplit, Co / ct, Ci / ct);
-    if (ct == 64) {
-        auto k = conv3x3_wgrad_kernel<64>;
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k, grid, dim3(256), sm, ST, p);
-    } else {
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, grid, dim3(256), sm, ST, p);
-    }
-    DTT_LAUNCH_CHECK();
-    return 0;
+    return wgrad_launch(dy, x, dw, nullptr, B, F, T, Ci, Co, stream);
+}
+
+// The same product with the workgroups' partial sums stored to a caller workspace and summed by a second launch
+// instead of fp32 atomics (a third of the kernel's time at 64 -> 64 channels).  dw is OVERWRITTEN (no zeroing
+// needed).  dtt_conv3x3_wgrad_ws_bytes: size of the workspace for a shape, 0 where the atomic form is the only one
+// (channel counts that are multiples of 32 but not of 64, other than 32 -> 32).
+extern "C" int64_t dtt_conv3x3_wgrad_ws_bytes(int B, int F, int T, int Ci, int Co) {
+    if (B <= 0 || F <= 0 || T <= 0 || Ci % 32 || Co % 32) return 0;
+    const WgGeom g = wg_geom(B, F, T, Ci, Co);
+    if (!g.c32 && g.ct != 64) return 0;
+    return (int64_t)g.nsplit * Co * 9 * Ci * 4;
+}
+extern "C" int dtt_conv3x3_wgrad_ws(const void* dy, const void* x, float* dw, void* ws, int64_t ws_bytes, int B, int F,
+                                    int T, int Ci, int Co, int dtype, void* stream) {
+    DTT_CHECK(dtype == 1, "dtt_conv3x3_wgrad_ws: bf16 only (fp32 goes through dtt_gemm)");
+    DTT_CHECK(B > 0 && F > 0 && T > 0 && Ci % 32 == 0 && Co % 32 == 0, "dtt_conv3x3_wgrad_ws: unsupported Ci=%d Co=%d", Ci, Co);
+    const int64_t need = dtt_conv3x3_wgrad_ws_bytes(B, F, T, Ci, Co);
+    DTT_CHECK(need > 0, "dtt_conv3x3_wgrad_ws: no workspace form for Ci=%d Co=%d (use dtt_conv3x3_wgrad)", Ci, Co);
+    DTT_CHECK(ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+              "dtt_conv3x3_wgrad_ws: workspace of %lld bytes needed", (long long)need);
+    return wgrad_launch(dy, x, dw, reinterpret_cast<float*>(ws), B, F, T, Ci, Co, stream);
 }

@@ -30,6 +30,7 @@ def lib():
         _lib.dtt_last_error.restype = C.c_char_p
         _lib.dtt_version.restype = C.c_int
         _lib.dtt_gemm_ws_bytes.restype = C.c_int64
+        _lib.dtt_conv3x3_wgrad_ws_bytes.restype = C.c_int64
     return _lib
 
 

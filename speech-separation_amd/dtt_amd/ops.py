@@ -425,9 +425,16 @@ def _conv_backward(kind, x, w, dy, need_dx, tile=True):
     _, _, _, gd, gw = _conv_geoms(kind, B, Fi, Ti, Ci, Co)
     if kind == "s1" and tile and _fast3(dy, Ci) and _fast3(x, Co):
         if x.dtype == torch.bfloat16:
-            dwp = _zeros_f32((Co, 9, Ci,), x.device)
-            check(lib().dtt_conv3x3_wgrad(ptr(dy), ptr(x), ptr(dwp), B, Fi, Ti, Ci, Co, 1, stream_ptr()),
-                  "dtt_conv3x3_wgrad")
+            need = lib().dtt_conv3x3_wgrad_ws_bytes(B, Fi, Ti, Ci, Co)
+            if need > 0:        # partial sums through a workspace + one sum launch instead of fp32 atomics
+                dwp = _empty((Co, 9, Ci), F32, x.device)
+                ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+                check(lib().dtt_conv3x3_wgrad_ws(ptr(dy), ptr(x), ptr(dwp), ptr(ws), C.c_int64(need), B, Fi, Ti, Ci, Co, 1,
+                                                 stream_ptr()), "dtt_conv3x3_wgrad_ws")
+            else:
+                dwp = _zeros_f32((Co, 9, Ci,), x.device)
+                check(lib().dtt_conv3x3_wgrad(ptr(dy), ptr(x), ptr(dwp), B, Fi, Ti, Ci, Co, 1, stream_ptr()),
+                      "dtt_conv3x3_wgrad")
         else:
             dwp = conv_wgrad(dy, x, gw, Co, Ci)
         dw = dwp.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()

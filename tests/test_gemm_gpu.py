@@ -266,6 +266,42 @@ def test_conv3x3_dedicated_kernels(dt, Ci, Co, Fq, T):
         dwp = torch.zeros(Co, 9, Ci, dtype=torch.float32, device=dev)
         check(lib().dtt_conv3x3_wgrad(ptr(_nhwc(dy).to(dev)), ptr(xd), ptr(dwp), Bn, Fq, T, Ci, Co, 1, stream_ptr()), "wgrad")
         assert rel_err(dwp, wr.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)) < TOL[dt]
+        # the workspace form (partial sums stored per split + one sum launch) overwrites dw: NaN-filled target,
+        # NaN-filled workspace, called twice; where it does not apply the size query says so
+        lib().dtt_conv3x3_wgrad_ws_bytes.restype = C.c_int64
+        need = lib().dtt_conv3x3_wgrad_ws_bytes(Bn, Fq, T, Ci, Co)
+        assert (need > 0) == ((Ci == 32 and Co == 32) or (Ci % 64 == 0 and Co % 64 == 0))
+        if need > 0:
+            dw2 = torch.full((Co, 9, Ci), float("nan"), dtype=torch.float32, device=dev)
+            ws = torch.full((need // 4,), float("nan"), dtype=torch.float32, device=dev)
+            for _ in range(2):
+                check(lib().dtt_conv3x3_wgrad_ws(ptr(_nhwc(dy).to(dev)), ptr(xd), ptr(dw2), ptr(ws), C.c_int64(need), Bn, Fq, T,
+                                                 Ci, Co, 1, stream_ptr()), "wgrad_ws")
+            assert rel_err(dw2, wr.grad.permute(0, 2, 3, 1).reshape(Co, 9, Ci)) < TOL[dt]
+            assert rel_err(dw2, dwp) < 1e-5
+            assert lib().dtt_conv3x3_wgrad_ws(ptr(_nhwc(dy).to(dev)), ptr(xd), ptr(dw2), ptr(ws), C.c_int64(need - 16), Bn, Fq,
+                                              T, Ci, Co, 1, stream_ptr()) != 0
+
+
+def test_conv3x3_wgrad_workspace_many_splits():
+    """The workspace weight gradient at shapes where every CU gets its own split (64 -> 64 at 16 x 257 x 63: 256
+    slabs; 512 -> 512: 4 slabs x 64 channel-tile pairs; 32 -> 32: 768 slabs) against the atomic form."""
+    import ctypes as C
+    from dtt_amd._lib import lib, check, ptr, stream_ptr
+    lib().dtt_conv3x3_wgrad_ws_bytes.restype = C.c_int64
+    g = torch.Generator().manual_seed(11)
+    for (Bn, Fq, T, Cc) in [(16, 257, 63, 64), (4, 65, 16, 512), (4, 513, 126, 32)]:
+        x = torch.randn(Bn, Fq, T, Cc, generator=g).to(torch.bfloat16).cuda()
+        dy = torch.randn(Bn, Fq, T, Cc, generator=g).to(torch.bfloat16).cuda()
+        ref = torch.zeros(Cc, 9, Cc, device="cuda")
+        check(lib().dtt_conv3x3_wgrad(ptr(dy), ptr(x), ptr(ref), Bn, Fq, T, Cc, Cc, 1, stream_ptr()), "wgrad")
+        need = lib().dtt_conv3x3_wgrad_ws_bytes(Bn, Fq, T, Cc, Cc)
+        assert need > 0
+        ws = torch.full((need // 4,), float("nan"), device="cuda")
+        dw = torch.full((Cc, 9, Cc), float("nan"), device="cuda")
+        check(lib().dtt_conv3x3_wgrad_ws(ptr(dy), ptr(x), ptr(dw), ptr(ws), C.c_int64(need), Bn, Fq, T, Cc, Cc, 1, stream_ptr()),
+              "wgrad_ws")
+        assert rel_err(dw, ref) < 1e-5, (Bn, Fq, T, Cc)
 
 
 

@@ -142,7 +142,12 @@ def colsum(x2d, rows, width, ld=None):
 
 
 def _in_chunk(B, P):
-    nch = max(1, min(P // 64 if P >= 64 else 1, max(1, 2048 // B)))
+    """Pixels per workgroup of the InstanceNorm reduction passes: ~2048 workgroups, chunks of >= 64 pixels, but
+    down to 16 pixels (one sweep at 512 channels) while that leaves fewer than 1024 workgroups."""
+    cap = max(1, 2048 // B)
+    nch = max(1, min(P // 64 if P >= 64 else 1, cap))
+    if B * nch < 1024:
+        nch = max(nch, min(max(1, P // 16), cap))
     return (P + nch - 1) // nch
 
 

@@ -724,6 +724,16 @@ int launch_fast(const DttGemm& p, hipStream_t st) {
 }
 
 template <typename T, int AK, int BKD> int dispatch_fast_tile(const DttGemm& p, hipStream_t st) {
+    // Small products (the fp32 token network of the cross-attention fusion: 800 x 256 x 256 and the like) leave most
+    // CUs idle at 128 x 128 tiles (4-16 workgroups, 35-57 us each on the fp32 MFMA path): with fewer than half a
+    // workgroup per CU take the 32 x 128 or 128 x 32 tile, whichever gives more workgroups (a quarter of the work
+    // per workgroup)
+    auto cd = [](int a, int b) { return (int64_t)((a + b - 1) / b); };
+    const int64_t zs = (int64_t)p.batch * p.splitk;
+    if (p.M > 64 && p.N > 64 && cd(p.M, 128) * cd(p.N, 128) * zs < 128) {
+        if (cd(p.M, 32) * cd(p.N, 128) >= cd(p.M, 128) * cd(p.N, 32)) return launch_fast<T, AK, BKD, 1, 4, 1, 1>(p, st);
+        return launch_fast<T, AK, BKD, 4, 1, 1, 1>(p, st);
+    }
     if (p.M <= 32 && p.N > 32) return launch_fast<T, AK, BKD, 1, 4, 1, 1>(p, st);
     if (p.M <= 64 && p.N > 64) return launch_fast<T, AK, BKD, 1, 4, 2, 1>(p, st);
     if (p.N <= 32) return launch_fast<T, AK, BKD, 4, 1, 1, 1>(p, st);

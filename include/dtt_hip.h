@@ -269,6 +269,11 @@ int dtt_sisnr_noalloc_max_floats(void);
  * (cross_attention_positional.py:55,77-78).
  * ------------------------------------------------------------------------- */
 int dtt_binary(int op, const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+/* Lip front end (resnet_video_encoder.py:33-37: Conv3d(1, 64, (5,7,7), stride (1,2,2), padding (2,3,3)) on a
+ * one-channel clip): the kt neighbouring frames of every frame stacked as channels, zero frames beyond the clip's ends,
+ * zero channels up to 8, channels-last -- out[(n T + t)][H][W][8] (dtype) from x[n][T][H][W] (fp32) in one pass; the
+ * Conv3d is then a per-frame Conv2d over this tensor. */
+int dtt_stack_frames(const float* x, void* out, int N, int T, int H, int W, int kt, int dtype, void* stream);
 /* Packed weight of the data-gradient conv of a stride-1 conv3x3 (autograd of F.conv2d, block_tfc_tdf.py:12-17):
  * w fp32 [Co][Ci][3][3] -> out [Ci][9][Co] with the taps rotated by 180 degrees, cast to dtype. */
 int dtt_pack_conv3_dgrad(const float* w, void* out, int Co, int Ci, int dtype, void* stream);

@@ -2,6 +2,7 @@
 // multiplicative U-Net skip (decoder.py:43), FiLM apply (block_fusion.py:30-37),
 // frequency-mean tokens and broadcast-concat of the cross-attention fusion
 // (cross_attention_positional.py:55,77-78).
+#include <algorithm>
 #include "common.h"
 #include "../../include/dtt_hip.h"
 
@@ -175,6 +176,37 @@ __global__ __launch_bounds__(NT) void pack_conv3_dgrad_kernel(const float* __res
 
 int ept_of(int dtype) { return dtype ? 8 : 4; }
 int grid_for(int64_t total) { int64_t g = (total + NT - 1) / NT; return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192); }
+// Lip front end: frames t - kt/2 .. t + kt/2 of a clip stacked as the channels of frame t (zero frames beyond the
+// clip's ends, zero channels up to 8), channels-last: out[(n T + t)][h][w][8] from x[n][T][H][W] fp32.  One lane =
+// one output pixel (16 bytes of bf16 / 32 of fp32); lanes run along w, so every one of the kt reads is coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void stack_frames_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int Tn,
+                                                           int HW, int kt) {
+    const int64_t total = (int64_t)N * Tn * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int hw = (int)(i % HW);
+        const int64_t nt = i / HW;
+        const int t = (int)(nt % Tn);
+        const int64_t n = nt / Tn;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ts = t + c - kt / 2;
+            v[c] = (c < kt && ts >= 0 && ts < Tn) ? x[(n * Tn + ts) * HW + hw] : 0.f;
+        }
+        if constexpr (sizeof(T) == 2) {
+            Vec16<bf16> o;
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) o.set2(c, v[c], v[c + 1]);
+            st16<bf16>(reinterpret_cast<bf16*>(out) + i * 8, o);
+        } else {
+            float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + i * 8);
+            d[0] = make_float4(v[0], v[1], v[2], v[3]);
+            d[1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
 }  // namespace
 
 #define ST reinterpret_cast<hipStream_t>(stream)
@@ -188,6 +220,16 @@ extern "C" int dtt_binary(int op, const void* a, const void* b, void* out, int64
     if (dtype) { if (op) BK(bf16, 1); else BK(bf16, 0); }
     else { if (op) BK(float, 1); else BK(float, 0); }
 #undef BK
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_stack_frames(const float* x, void* out, int N, int T, int H, int W, int kt, int dtype, void* stream) {
+    DTT_CHECK(x && out && N > 0 && T > 0 && H > 0 && W > 0 && kt >= 1 && kt <= 8 && (kt & 1), "dtt_stack_frames: bad shape (kt=%d)", kt);
+    const int64_t total = (int64_t)N * T * H * W;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    if (dtype) hipLaunchKernelGGL(stack_frames_kernel<bf16>, dim3(grid), dim3(256), 0, ST, x, (bf16*)out, N, T, H * W, kt);
+    else hipLaunchKernelGGL(stack_frames_kernel<float>, dim3(grid), dim3(256), 0, ST, x, (float*)out, N, T, H * W, kt);
     DTT_LAUNCH_CHECK();
     return 0;
 }

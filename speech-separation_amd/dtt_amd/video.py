@@ -142,14 +142,27 @@ class VideoEncoder(nn.Module):
         conv, bn = self.frontend3D[0], self.frontend3D[1]
         Bp, _, T, H, W = x.shape
         kt = conv.kernel_size[0]
-        xp = nn.functional.pad(x[:, 0], (0, 0, 0, 0, kt // 2, kt // 2))            # [B', T + 4, H, W]
-        x5 = xp.unfold(1, kt, 1).permute(0, 1, 4, 2, 3).reshape(Bp * T, kt, H, W)   # frames t-2 .. t+2 as channels
         w2 = conv.weight[:, 0]                                                    # [64, 5, 7, 7]
         cpad = (-kt) % 8                                                          # channel count to a multiple of 8
+        if kt <= 8 and kt % 2 == 1 and x.dtype == torch.float32 and not x.requires_grad:
+            # one pass: fp32 clip -> stacked, channel-padded, channels-last frames in the conv's dtype (the torch
+            # route below is five copies of a 200 MB tensor: pad, unfold, channel pad, layout, autocast)
+            from . import ops
+            odt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+            if odt not in (torch.bfloat16, torch.float32):
+                odt = torch.float32
+            buf = torch.empty((Bp * T, H, W, 8), dtype=odt, device=x.device)
+            ops.check(ops.lib().dtt_stack_frames(ops.ptr(x.contiguous()), ops.ptr(buf), Bp, T, H, W, kt,
+                                                 1 if odt == torch.bfloat16 else 0, ops.stream_ptr()), "dtt_stack_frames")
+            x5 = buf.permute(0, 3, 1, 2)                                          # NCHW view of channels-last memory
+        else:
+            xp = nn.functional.pad(x[:, 0], (0, 0, 0, 0, kt // 2, kt // 2))        # [B', T + 4, H, W]
+            x5 = xp.unfold(1, kt, 1).permute(0, 1, 4, 2, 3).reshape(Bp * T, kt, H, W)   # frames t-2 .. t+2 as channels
+            if cpad:
+                x5 = nn.functional.pad(x5, (0, 0, 0, 0, 0, cpad))
+            x5 = x5.contiguous(memory_format=torch.channels_last)
         if cpad:
-            x5 = nn.functional.pad(x5, (0, 0, 0, 0, 0, cpad))
             w2 = nn.functional.pad(w2, (0, 0, 0, 0, 0, cpad))
-        x5 = x5.contiguous(memory_format=torch.channels_last)
         y = nn.functional.conv2d(x5, w2, None, stride=conv.stride[1:], padding=conv.padding[1:])
         y = batch_norm_act(y, bn, 1)
         return MaxPool3x3s2.apply(y), T

@@ -362,3 +362,21 @@ def test_cross_attention_core_mfma_tiles(B, Tq, Tk, Cc, heads):
     out.backward(do.to(DEV))
     for a, b in ((qd, qr), (kd, kr), (vd, vr)):
         assert rel_err(a.grad, b.grad) < 2e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_stack_frames_matches_pad_unfold(dt):
+    """dtt_stack_frames (frames t-2 .. t+2 as channels, zero beyond the clip, zero channels 5..7, channels-last) against
+    the torch route it replaces (pad -> unfold -> permute -> channel pad -> cast): bit-exact."""
+    from dtt_amd import ops
+    g = torch.Generator().manual_seed(21)
+    N, T, H, W, kt = 3, 7, 12, 10, 5
+    x = torch.randn(N, T, H, W, generator=g).to(DEV)
+    out = torch.full((N * T, H, W, 8), float("nan"), dtype=dt, device=DEV)
+    ops.check(ops.lib().dtt_stack_frames(ops.ptr(x), ops.ptr(out), N, T, H, W, kt, 1 if dt == torch.bfloat16 else 0,
+                                         ops.stream_ptr()), "dtt_stack_frames")
+    xp = F.pad(x, (0, 0, 0, 0, kt // 2, kt // 2))
+    ref = xp.unfold(1, kt, 1).permute(0, 1, 4, 2, 3).reshape(N * T, kt, H, W)
+    ref = F.pad(ref, (0, 0, 0, 0, 0, 8 - kt)).permute(0, 2, 3, 1).to(dt)
+    assert torch.equal(out, ref)
+

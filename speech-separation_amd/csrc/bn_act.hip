@@ -92,43 +92,52 @@ __device__ __forceinline__ void reduce_ch(const float (&v)[EPT], float* red, flo
     __syncthreads();
 }
 
-// batch statistics, pass 1: partial[chunk][C][2] = {mean, M2} of the chunk's pixels (second sweep is L2-hot)
+// batch statistics, pass 1: partial[chunk][C][2] = {mean, M2} of the chunk's pixels in ONE sweep: sums of (x - pivot)
+// and (x - pivot)^2 with the chunk's first pixel as the pivot (M2 = S2 - S1^2 / n; the pivot keeps S1^2 / n small
+// against S2).  The two-sweep form read the tensor twice from HBM: 512 chunks of a 400 MB tensor are not L2-resident.
 template <typename T>
 __global__ __launch_bounds__(NT) void bn_stats_partial(const T* __restrict__ x, float* __restrict__ partial, int P, int C,
                                                        int chunk) {
-    constexpr int EPT = Vec16<T>::N;
+    constexpr int EPT = Vec16<T>::N, U = 4;
     extern __shared__ float sm[];
     float* red = sm;
     float* chv = sm + NT * EPT;
     const int cpp = C / EPT, ppi = NT / cpp, nact = ppi * cpp;
     const int tid = threadIdx.x, pl = tid / cpp, cq = tid % cpp;
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
-    const T* base = x + cq * EPT;
-    float acc[EPT], mean[EPT];
+    const T* base = x + (cq % cpp) * EPT;
+    float s1[EPT], s2[EPT], piv[EPT];
+    {
+        const Vec16<T> pv = ld16<T>(base + (int64_t)p0 * C);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
+        for (int e = 0; e < EPT; ++e) { piv[e] = pv.get(e); s1[e] = 0.f; s2[e] = 0.f; }
+    }
     if (tid < nact)
-        for (int p = p0 + pl; p < p1; p += ppi) {
-            const Vec16<T> v = ld16<T>(base + (int64_t)p * C);
+        for (int p = p0 + pl; p < p1; p += U * ppi) {
+            Vec16<T> v[U];
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) acc[e] += v.get(e);
+            for (int u = 0; u < U; ++u) v[u] = ld16_pred<T>(base + (int64_t)(p + u * ppi) * C, base + (int64_t)p0 * C, p + u * ppi < p1);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const float d = (p + u * ppi < p1) ? v[u].get(e) - piv[e] : 0.f;
+                    s1[e] += d; s2[e] += d * d;
+                }
         }
-    reduce_ch<EPT>(acc, red, chv, cpp, nact, C);
     const float inv = 1.f / (float)(p1 - p0);
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) { mean[e] = chv[cq * EPT + e] * inv; acc[e] = 0.f; }
-    if (tid < nact)
-        for (int p = p0 + pl; p < p1; p += ppi) {
-            const Vec16<T> v = ld16<T>(base + (int64_t)p * C);
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) { const float d = v.get(e) - mean[e]; acc[e] += d * d; }
-        }
     float* dst = partial + ((int64_t)blockIdx.x * C) * 2;
+    reduce_ch<EPT>(s1, red, chv, cpp, nact, C);
+    float t1[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) t1[e] = chv[(cq % cpp) * EPT + e];
+    reduce_ch<EPT>(s2, red, chv, cpp, nact, C);
     if (tid < cpp)
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) dst[(cq * EPT + e) * 2] = mean[e];
-    reduce_ch<EPT>(acc, red, chv, cpp, nact, C);
-    for (int c = tid; c < C; c += NT) dst[c * 2 + 1] = chv[c];
+        for (int e = 0; e < EPT; ++e) {
+            dst[(cq * EPT + e) * 2] = piv[e] + t1[e] * inv;
+            dst[(cq * EPT + e) * 2 + 1] = fmaxf(chv[cq * EPT + e] - t1[e] * t1[e] * inv, 0.f);
+        }
 }
 
 // pass 2: Chan merge of the chunk partials, FG lane groups per channel each walking every FG-th chunk, then a

@@ -402,8 +402,8 @@ int dtt_gemm256_try(const DttGemm& p, hipStream_t st) {
     if (kc) {
         // plain store, k-contiguous operands
         if (p.splitk != 1 || p.atomic || p.a_ms % 8 || p.b_ns % 8 || p.N % 8 || p.c_ms % 8 || p.bias_mode > 1 ||
-            (p.R && (p.r_ns != 1 || p.r_ms % 8 || !al(p.R))) || tiles < 192)
-            return 1;                                      // fewer tiles than CUs: the 128 x 128 form fills the chip better
+            (p.R && (p.r_ns != 1 || p.r_ms % 8 || !al(p.R))) || tiles < 128)
+            return 1;                                      // under half a tile per CU: the 128 x 128 form fills the chip better
         DttGemm q = p;
         q.ws = nullptr;
         hipLaunchKernelGGL(gemm256_kernel<false>, dim3((unsigned)tiles), dim3(512), sm, st, q);

@@ -72,6 +72,14 @@ typedef struct DttGemm {
      * small: atomics.  Contents are undefined afterwards; calls sharing one workspace must be stream-ordered.   */
     void* ws;
     int64_t ws_bytes;
+    /* general conv geometry of the gather modes (0 = the 3x3 / pad 1 taps above): kernel width cKW, zero padding
+     * cPadF rows above / cPadT columns left; source pixel of tap (kh, kw) = (fo * cstride + kh - cPadF,
+     * to * cstride + kw - cPadT), non-transposed only.  a_mode 1: k = (kh * cKW + kw) * cCi + ci, K a multiple of
+     * cKW * cCi.  b_mode 1: batch = 1 and n = kh * (cKW * cCi) + (kw * cCi + ci): the cKW pixels of a kernel row are
+     * read as ONE contiguous run of cKW * cCi elements starting at the tap's first pixel, so the caller pads the
+     * input's columns (cPadT = 0, cTi = padded width) -- only rows are predicated.  Used for the lip front end
+     * (resnet_video_encoder.py:33-37: 7 x 7 / stride 2 over 5 stacked frames, dtt_stack_frames). */
+    int32_t cKW, cPadF, cPadT, reserved2_;
 } DttGemm;
 int dtt_gemm(const DttGemm* p, void* stream);
 /* bytes of workspace with which dtt_gemm(p) would take the store-and-sum split-K path; 0: it has no use for one */
@@ -271,9 +279,11 @@ int dtt_sisnr_noalloc_max_floats(void);
 int dtt_binary(int op, const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 /* Lip front end (resnet_video_encoder.py:33-37: Conv3d(1, 64, (5,7,7), stride (1,2,2), padding (2,3,3)) on a
  * one-channel clip): the kt neighbouring frames of every frame stacked as channels, zero frames beyond the clip's ends,
- * zero channels up to 8, channels-last -- out[(n T + t)][H][W][8] (dtype) from x[n][T][H][W] (fp32) in one pass; the
- * Conv3d is then a per-frame Conv2d over this tensor. */
-int dtt_stack_frames(const float* x, void* out, int N, int T, int H, int W, int kt, int dtype, void* stream);
+ * zero channels up to 8, channels-last, pad_left / pad_right zero columns around every row --
+ * out[(n T + t)][H][pad_left + W + pad_right][8] (dtype) from x[n][T][H][W] (fp32) in one pass; the Conv3d is then a
+ * per-frame Conv2d over this tensor (dtt_gemm with the general conv geometry cKW / cPadF / cPadT). */
+int dtt_stack_frames(const float* x, void* out, int N, int T, int H, int W, int kt, int pad_left, int pad_right, int dtype,
+                     void* stream);
 /* Packed weight of the data-gradient conv of a stride-1 conv3x3 (autograd of F.conv2d, block_tfc_tdf.py:12-17):
  * w fp32 [Co][Ci][3][3] -> out [Ci][9][Co] with the taps rotated by 180 degrees, cast to dtype. */
 int dtt_pack_conv3_dgrad(const float* w, void* out, int Co, int Ci, int dtype, void* stream);

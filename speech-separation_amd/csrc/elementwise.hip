@@ -177,22 +177,27 @@ __global__ __launch_bounds__(NT) void pack_conv3_dgrad_kernel(const float* __res
 int ept_of(int dtype) { return dtype ? 8 : 4; }
 int grid_for(int64_t total) { int64_t g = (total + NT - 1) / NT; return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192); }
 // Lip front end: frames t - kt/2 .. t + kt/2 of a clip stacked as the channels of frame t (zero frames beyond the
-// clip's ends, zero channels up to 8), channels-last: out[(n T + t)][h][w][8] from x[n][T][H][W] fp32.  One lane =
-// one output pixel (16 bytes of bf16 / 32 of fp32); lanes run along w, so every one of the kt reads is coalesced.
+// clip's ends, zero channels up to 8), channels-last, with padl / padr zero columns on either side of every row:
+// out[(n T + t)][h][padl + W + padr][8] from x[n][T][H][W] fp32.  One lane = one output pixel (16 bytes of bf16 / 32
+// of fp32); lanes run along w, so every one of the kt reads is coalesced.
 template <typename T>
 __global__ __launch_bounds__(256) void stack_frames_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int Tn,
-                                                           int HW, int kt) {
-    const int64_t total = (int64_t)N * Tn * HW;
+                                                           int H, int W, int padl, int padr, int kt) {
+    const int Wp = padl + W + padr;
+    const int64_t total = (int64_t)N * Tn * H * Wp;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int hw = (int)(i % HW);
-        const int64_t nt = i / HW;
-        const int t = (int)(nt % Tn);
-        const int64_t n = nt / Tn;
+        const int wp = (int)(i % Wp), w = wp - padl;
+        int64_t r = i / Wp;
+        const int h = (int)(r % H); r /= H;
+        const int t = (int)(r % Tn);
+        const int64_t n = r / Tn;
+        const bool inside = w >= 0 && w < W;
+        const int hw = h * W + (inside ? w : 0), HW = H * W;
         float v[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int ts = t + c - kt / 2;
-            v[c] = (c < kt && ts >= 0 && ts < Tn) ? x[(n * Tn + ts) * HW + hw] : 0.f;
+            v[c] = (inside && c < kt && ts >= 0 && ts < Tn) ? x[(n * Tn + ts) * HW + hw] : 0.f;
         }
         if constexpr (sizeof(T) == 2) {
             Vec16<bf16> o;
@@ -224,12 +229,14 @@ extern "C" int dtt_binary(int op, const void* a, const void* b, void* out, int64
     return 0;
 }
 
-extern "C" int dtt_stack_frames(const float* x, void* out, int N, int T, int H, int W, int kt, int dtype, void* stream) {
-    DTT_CHECK(x && out && N > 0 && T > 0 && H > 0 && W > 0 && kt >= 1 && kt <= 8 && (kt & 1), "dtt_stack_frames: bad shape (kt=%d)", kt);
-    const int64_t total = (int64_t)N * T * H * W;
+extern "C" int dtt_stack_frames(const float* x, void* out, int N, int T, int H, int W, int kt, int pad_left, int pad_right,
+                                int dtype, void* stream) {
+    DTT_CHECK(x && out && N > 0 && T > 0 && H > 0 && W > 0 && kt >= 1 && kt <= 8 && (kt & 1) && pad_left >= 0 && pad_right >= 0,
+              "dtt_stack_frames: bad shape (kt=%d)", kt);
+    const int64_t total = (int64_t)N * T * H * (pad_left + W + pad_right);
     const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
-    if (dtype) hipLaunchKernelGGL(stack_frames_kernel<bf16>, dim3(grid), dim3(256), 0, ST, x, (bf16*)out, N, T, H * W, kt);
-    else hipLaunchKernelGGL(stack_frames_kernel<float>, dim3(grid), dim3(256), 0, ST, x, (float*)out, N, T, H * W, kt);
+    if (dtype) hipLaunchKernelGGL(stack_frames_kernel<bf16>, dim3(grid), dim3(256), 0, ST, x, (bf16*)out, N, T, H, W, pad_left, pad_right, kt);
+    else hipLaunchKernelGGL(stack_frames_kernel<float>, dim3(grid), dim3(256), 0, ST, x, (float*)out, N, T, H, W, pad_left, pad_right, kt);
     DTT_LAUNCH_CHECK();
     return 0;
 }

@@ -530,8 +530,8 @@ struct FastLoader {
         }
     }
     // OP_WG: k = output pixel of the conv, rows = input channels of the pixel that tap `wtap` reads
-    int wtap, wrow[NIT];
-    __device__ __forceinline__ void init_wg(const T* base, int r0, int rmax, int tap) {
+    int wtap, wrow[NIT], wkh[NIT];
+    __device__ __forceinline__ void init_wg(const T* base, int r0, int rmax, int tap, int runlen) {
         safe = base; ragged = false; step = 0; wtap = tap;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -540,6 +540,8 @@ struct FastLoader {
             rok[it] = r0 + rc * EPT < rmax;
             kofs[it] = kl;
             wrow[it] = rok[it] ? r0 + rc * EPT : 0;
+            wkh[it] = 0;
+            if (runlen) { wkh[it] = wrow[it] / runlen; wrow[it] -= wkh[it] * runlen; }   // general geometry: n -> (kh, run offset)
             src[it] = base;
         }
     }
@@ -552,7 +554,12 @@ struct FastLoader {
             const int b = pix / (p.cFo * p.cTo); pix -= b * p.cFo * p.cTo;
             const int fo = pix / p.cTo, to = pix - fo * p.cTo;
             int fi, ti;
-            ok = conv_src(p, fo, to, wtap, fi, ti) && ok;
+            if (p.cKW) {
+                fi = fo * p.cstride + wkh[it] - p.cPadF; ti = to * p.cstride - p.cPadT;
+                ok = ok && fi >= 0 && fi < p.cFi && ti >= 0 && ti + p.cKW <= p.cTi;
+            } else {
+                ok = conv_src(p, fo, to, wtap, fi, ti) && ok;
+            }
             regs[it] = ld16_pred<T>(src[it] + ((int64_t)(b * p.cFi + fi) * p.cTi + ti) * p.cCi + wrow[it], safe, ok);
         }
     }
@@ -569,10 +576,12 @@ struct FastLoader {
             const int tap = ci_pow2 ? gk >> ci_sh : gk / p.cCi, ci = gk - tap * p.cCi;
             int kh, kw;
             if (p.cphase) { const int nkw = pt ? 2 : 1, ih = tap / nkw; kh = pf ? 2 * ih : 1; kw = pt ? 2 * (tap - ih * nkw) : 1; }
+            else if (p.cKW) { kh = tap / p.cKW; kw = tap - kh * p.cKW; }
             else { kh = tap / 3; kw = tap - kh * 3; }
             int fi, ti;
             if (!p.ctrans) {
-                fi = pfo[it] * p.cstride + kh - 1; ti = pto[it] * p.cstride + kw - 1;
+                const int padf = p.cKW ? p.cPadF : 1, padt = p.cKW ? p.cPadT : 1;
+                fi = pfo[it] * p.cstride + kh - padf; ti = pto[it] * p.cstride + kw - padt;
                 ok = ok && fi >= 0 && fi < p.cFi && ti >= 0 && ti < p.cTi;
             } else {
                 const int a = pfo[it] + 1 - kh, bb = pto[it] + 1 - kw;
@@ -683,7 +692,7 @@ __global__ __launch_bounds__(256, GEMM_MINB) void gemm_fast_kernel(const DttGemm
     LB lb;
     if constexpr (AK == OP_CONV) la.init_conv(p, reinterpret_cast<const T*>(p.A), m0, p.M);
     else la.init(reinterpret_cast<const T*>(p.A) + (int64_t)bz * p.a_bs, p.a_ms, p.a_ks, m0, p.M, kt0 * BK, 0);
-    if constexpr (BKD == OP_WG) lb.init_wg(reinterpret_cast<const T*>(p.B), n0, p.N, bz);
+    if constexpr (BKD == OP_WG) lb.init_wg(reinterpret_cast<const T*>(p.B), n0, p.N, bz, p.cKW ? p.cKW * p.cCi : 0);
     else lb.init(reinterpret_cast<const T*>(p.B) + (int64_t)bz * p.b_bs, p.b_ns, p.b_ks, n0, p.N, kt0 * BK,
                  BKD == OP_RCS ? p.sh_shift : 0);
     la.ragged = lb.ragged = (p.K % MM<T>::EPT) != 0;
@@ -828,13 +837,23 @@ extern "C" int dtt_gemm(const DttGemm* pp, void* stream) {
                       p.M == p.cB * ((p.cFo - pf + 1) / 2) * ((p.cTo - pt + 1) / 2),
                   "dtt_gemm: parity-phase geometry mismatch (K=%d M=%d)", p.K, p.M);
         DTT_CHECK(p.cCi % (p.dtype ? 8 : 4) == 0, "dtt_gemm: conv Ci=%d must be a multiple of 16 bytes", p.cCi);
+    } else if (p.a_mode == 1 && p.cKW) {
+        DTT_CHECK(p.cKW > 0 && p.cCi > 0 && p.K % (p.cKW * p.cCi) == 0 && p.M == p.cB * p.cFo * p.cTo && !p.ctrans &&
+                      p.cPadF >= 0 && p.cPadT >= 0 && p.cstride >= 1,
+                  "dtt_gemm: general conv geometry mismatch (K=%d KW=%d Ci=%d M=%d)", p.K, p.cKW, p.cCi, p.M);
+        DTT_CHECK(p.cCi % (p.dtype ? 8 : 4) == 0, "dtt_gemm: conv Ci=%d must be a multiple of 16 bytes", p.cCi);
     } else if (p.a_mode == 1) {
         DTT_CHECK(p.K == 9 * p.cCi && p.M == p.cB * p.cFo * p.cTo, "dtt_gemm: conv geometry mismatch (K=%d Ci=%d M=%d)",
                   p.K, p.cCi, p.M);
         DTT_CHECK(p.cCi % (p.dtype ? 8 : 4) == 0, "dtt_gemm: conv Ci=%d must be a multiple of 16 bytes", p.cCi);
         DTT_CHECK(!p.ctrans || p.cstride == 2, "dtt_gemm: transposed conv needs stride 2");
     }
-    if (p.b_mode == 1) {
+    if (p.b_mode == 1 && p.cKW) {
+        DTT_CHECK(p.K == p.cB * p.cFo * p.cTo && p.batch == 1 && p.N % (p.cKW * p.cCi) == 0 && p.b_ns == 1 && p.cPadF >= 0 &&
+                      p.cPadT >= 0 && p.cstride >= 1,
+                  "dtt_gemm: general wgrad geometry mismatch");
+        DTT_CHECK(!p.ctrans, "dtt_gemm: wgrad gather is always the strided (non-transposed) form");
+    } else if (p.b_mode == 1) {
         DTT_CHECK(p.K == p.cB * p.cFo * p.cTo && p.batch == 9 && p.N == p.cCi && p.b_ns == 1,
                   "dtt_gemm: wgrad geometry mismatch");
         DTT_CHECK(!p.ctrans, "dtt_gemm: wgrad gather is always the strided (non-transposed) form");
@@ -845,5 +864,6 @@ extern "C" int dtt_gemm(const DttGemm* pp, void* stream) {
     if (rc != 1) return rc;
     rc = p.dtype == 1 ? dispatch_fast<bf16>(p, st) : dispatch_fast<float>(p, st);
     if (rc != 1) return rc;
+    DTT_CHECK(!p.cKW, "dtt_gemm: the general conv geometry (cKW) needs 16-byte aligned, n-contiguous operands (fast kernels only)");
     return p.dtype == 1 ? dispatch<bf16>(p, st) : dispatch<float>(p, st);
 }

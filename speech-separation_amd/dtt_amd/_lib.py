@@ -75,6 +75,7 @@ class DttGemm(C.Structure):
         ("sh_shift", C.c_int32), ("sh_heads", C.c_int32), ("sh_L", C.c_int32), ("sh_edge", C.c_int32),
         ("cphase", C.c_int32), ("reserved_", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("cKW", C.c_int32), ("cPadF", C.c_int32), ("cPadT", C.c_int32), ("reserved2_", C.c_int32),
     ]
 
 

@@ -552,6 +552,48 @@ class Conv3x3(torch.autograd.Function):
         return (dx.permute(0, 3, 1, 2) if dx is not None else None), dw
 
 
+class FrontConv(torch.autograd.Function):
+    """The lip front end's Conv3d(1, Co, (kt, 7, 7), stride (1, 2, 2), padding (kt // 2, 3, 3), bias=False)
+    (resnet_video_encoder.py:33-37) as implicit GEMMs over the stacked-frame tensor of dtt_stack_frames:
+    x5p [frames, H, 3 + W + 5, 8] (kt <= 8 neighbouring frames as channels, zero columns around every row), w
+    [Co, 1, kt, 7, 7] fp32 -> y [frames, H/2, W/2, Co].  A kernel row (8 pixels of 8 channels, the eighth pixel and
+    the channels >= kt with zero weights) is 128 contiguous bytes of x5p: forward K = 7 rows x 64, weight gradient
+    N = 7 x 64 with the pixels as K (dtt_gemm's general conv geometry).  No input gradient (the clip is data).
+    MIOpen: 707 us forward + 777 us weight gradient at 1600 frames of 88 x 88."""
+
+    @staticmethod
+    def forward(ctx, x5p, w, H, W):
+        NF, Hx, Wp, Cc = x5p.shape
+        Co, _, kt, KH, KWr = w.shape
+        Ho, Wo = (H + 6 - KH) // 2 + 1, (W + 6 - KWr) // 2 + 1
+        if not (Hx == H and Cc == 8 and KWr <= 8 and kt <= 8 and Wp >= 2 * (Wo - 1) + 8 and Wp >= W + 3):
+            raise DttError("FrontConv: input is not a dtt_stack_frames tensor padded by (3, >= 5) columns")
+        dt = x5p.dtype
+        wp = torch.zeros((Co, KH, 8, 8), dtype=dt, device=w.device)
+        wp[:, :, :KWr, :kt] = w[:, 0].permute(0, 2, 3, 1)
+        geom = dict(cB=NF, cFi=H, cTi=Wp, cCi=8, cFo=Ho, cTo=Wo, cstride=2, ctrans=0, cKW=8, cPadF=3, cPadT=0)
+        y = _empty((NF, Ho, Wo, Co), dt, x5p.device)
+        gemm_raw(A=x5p, B=wp, C=y, M=NF * Ho * Wo, N=Co, K=KH * 64, a_ms=0, a_ks=1, b_ks=1, b_ns=KH * 64, c_ms=Co, c_ns=1,
+                 dtype=_dt(x5p), a_mode=1, **geom)
+        ctx.save_for_backward(x5p)
+        ctx.geom, ctx.wshape = geom, tuple(w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x5p,) = ctx.saved_tensors
+        Co, _, kt, KH, KWr = ctx.wshape
+        g = ctx.geom
+        dy = dy.contiguous()
+        P, N = g["cB"] * g["cFo"] * g["cTo"], KH * 64
+        dwp = _zeros_f32((Co, N), dy.device)
+        tiles = -(-Co // 64) * -(-N // 128)
+        gemm_raw(A=dy, B=x5p, C=dwp, M=Co, N=N, K=P, splitk=max(1, min(256, 512 // tiles)), a_ms=1, a_ks=Co, b_ks=N, b_ns=1,
+                 c_ms=N, c_ns=1, dtype=_dt(dy), atomic=1, out_f32=1, b_mode=1, **g)
+        dw = dwp.view(Co, KH, 8, 8)[:, :, :KWr, :kt].permute(0, 3, 1, 2).unsqueeze(1).contiguous()
+        return None, dw, None, None
+
+
 # --------------------------------------------------------------------------- #
 # TDF: two Linears on the frequency axis + residual (block_tfc_tdf.py:23-26,43-44)
 # --------------------------------------------------------------------------- #

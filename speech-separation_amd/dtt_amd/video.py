@@ -17,7 +17,8 @@ from torch import nn
 
 _NATIVE_BN = os.environ.get("DTT_VIDEO_NATIVE_BN", "1") == "1"
 _FUSED_BN = os.environ.get("DTT_VIDEO_FUSED_BN", "1") == "1"      # 0: ATen BatchNorm + elementwise Swish (A/B switch)
-_OWN_CONV = os.environ.get("DTT_VIDEO_OWN_CONV", "1") == "1"      # 0: every trunk convolution on MIOpen (A/B switch)
+_OWN_CONV = os.environ.get("DTT_VIDEO_OWN_CONV", "1") == "1"      # 0: every lip-encoder convolution on MIOpen (A/B switch)
+_OWN_FRONT = os.environ.get("DTT_VIDEO_FRONT_CONV", "1") == "1"   # 0: only the front-end convolution on MIOpen
 
 
 def _conv3x3(conv, x):
@@ -151,9 +152,16 @@ class VideoEncoder(nn.Module):
             odt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
             if odt not in (torch.bfloat16, torch.float32):
                 odt = torch.float32
-            buf = torch.empty((Bp * T, H, W, 8), dtype=odt, device=x.device)
-            ops.check(ops.lib().dtt_stack_frames(ops.ptr(x.contiguous()), ops.ptr(buf), Bp, T, H, W, kt,
+            own = (_OWN_CONV and _OWN_FRONT and conv.kernel_size[1:] == (7, 7) and conv.stride == (1, 2, 2) and conv.padding[1:] == (3, 3)
+                   and H % 2 == 0 and W % 2 == 0)
+            padl, padr = (3, 5) if own else (0, 0)         # own conv: zero columns instead of per-pixel predicates
+            buf = torch.empty((Bp * T, H, padl + W + padr, 8), dtype=odt, device=x.device)
+            ops.check(ops.lib().dtt_stack_frames(ops.ptr(x.contiguous()), ops.ptr(buf), Bp, T, H, W, kt, padl, padr,
                                                  1 if odt == torch.bfloat16 else 0, ops.stream_ptr()), "dtt_stack_frames")
+            if own:
+                y = ops.FrontConv.apply(buf, conv.weight, H, W).permute(0, 3, 1, 2)   # NCHW view of channels-last memory
+                y = batch_norm_act(y, bn, 1)
+                return MaxPool3x3s2.apply(y), T
             x5 = buf.permute(0, 3, 1, 2)                                          # NCHW view of channels-last memory
         else:
             xp = nn.functional.pad(x[:, 0], (0, 0, 0, 0, kt // 2, kt // 2))        # [B', T + 4, H, W]

@@ -365,18 +365,44 @@ def test_cross_attention_core_mfma_tiles(B, Tq, Tk, Cc, heads):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_stack_frames_matches_pad_unfold(dt):
-    """dtt_stack_frames (frames t-2 .. t+2 as channels, zero beyond the clip, zero channels 5..7, channels-last) against
-    the torch route it replaces (pad -> unfold -> permute -> channel pad -> cast): bit-exact."""
+@pytest.mark.parametrize("padl,padr", [(0, 0), (3, 5)])
+def test_stack_frames_matches_pad_unfold(dt, padl, padr):
+    """dtt_stack_frames (frames t-2 .. t+2 as channels, zero beyond the clip, zero channels 5..7, channels-last, zero
+    columns around every row) against the torch route it replaces (pad -> unfold -> permute -> channel pad -> cast):
+    bit-exact."""
     from dtt_amd import ops
     g = torch.Generator().manual_seed(21)
     N, T, H, W, kt = 3, 7, 12, 10, 5
     x = torch.randn(N, T, H, W, generator=g).to(DEV)
-    out = torch.full((N * T, H, W, 8), float("nan"), dtype=dt, device=DEV)
-    ops.check(ops.lib().dtt_stack_frames(ops.ptr(x), ops.ptr(out), N, T, H, W, kt, 1 if dt == torch.bfloat16 else 0,
-                                         ops.stream_ptr()), "dtt_stack_frames")
+    out = torch.full((N * T, H, padl + W + padr, 8), float("nan"), dtype=dt, device=DEV)
+    ops.check(ops.lib().dtt_stack_frames(ops.ptr(x), ops.ptr(out), N, T, H, W, kt, padl, padr,
+                                         1 if dt == torch.bfloat16 else 0, ops.stream_ptr()), "dtt_stack_frames")
     xp = F.pad(x, (0, 0, 0, 0, kt // 2, kt // 2))
     ref = xp.unfold(1, kt, 1).permute(0, 1, 4, 2, 3).reshape(N * T, kt, H, W)
-    ref = F.pad(ref, (0, 0, 0, 0, 0, 8 - kt)).permute(0, 2, 3, 1).to(dt)
+    ref = F.pad(ref, (padl, padr, 0, 0, 0, 8 - kt)).permute(0, 2, 3, 1).to(dt)
     assert torch.equal(out, ref)
 
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_front_conv_against_conv3d(dt, tol):
+    """ops.FrontConv (the 5 x 7 x 7 / stride (1,2,2) front-end convolution as implicit GEMMs over the stacked-frame
+    tensor, general conv geometry of dtt_gemm) against torch's Conv3d in float64: output and weight gradient."""
+    from dtt_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, T, H, W, Co, kt = 2, 6, 20, 16, 64, 5
+    x = torch.randn(N, T, H, W, generator=g)
+    w = torch.randn(Co, 1, kt, 7, 7, generator=g) / (kt * 49) ** 0.5
+    buf = torch.empty((N * T, H, W + 8, 8), dtype=dt, device=DEV)
+    ops.check(ops.lib().dtt_stack_frames(ops.ptr(x.to(DEV)), ops.ptr(buf), N, T, H, W, kt, 3, 5,
+                                         1 if dt == torch.bfloat16 else 0, ops.stream_ptr()), "dtt_stack_frames")
+    wd = w.to(DEV).requires_grad_(True)
+    y = ops.FrontConv.apply(buf, wd, H, W)                                   # [N*T, H/2, W/2, Co]
+    xr = x.to(dt).double()[:, None]                                          # the kernel sees x rounded to dt
+    wr = (w.to(dt) if dt == torch.bfloat16 else w).double().requires_grad_(True)
+    ref = F.conv3d(xr, wr, None, stride=(1, 2, 2), padding=(kt // 2, 3, 3))  # [N, Co, T, H/2, W/2]
+    refl = ref.permute(0, 2, 3, 4, 1).reshape(N * T, H // 2, W // 2, Co)
+    assert rel_err(y.float().cpu(), refl.detach()) < tol
+    gy = torch.randn(refl.shape, generator=g).to(dt)
+    y.backward(gy.to(DEV))
+    ref.backward(gy.double().reshape(N, T, H // 2, W // 2, Co).permute(0, 4, 1, 2, 3))
+    assert rel_err(wd.grad.cpu(), wr.grad) < tol

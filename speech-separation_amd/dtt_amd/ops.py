@@ -60,10 +60,11 @@ def reset_zero_arena():
 # --------------------------------------------------------------------------- #
 # thin wrappers over the C entry points
 # --------------------------------------------------------------------------- #
-def conv_gemm(x, wp, bias, out, geom, res=None):
-    """Implicit-GEMM 3x3 conv: x [B,Fi,Ti,Ci] -> out [B,Fo,To,Co]; wp [Co][9*Ci]."""
+def conv_gemm(x, wp, bias, out, geom, res=None, phases=False):
+    """Implicit-GEMM 3x3 conv: x [B,Fi,Ti,Ci] -> out [B,Fo,To,Co]; wp [Co][9*Ci].  phases: force the four-parity
+    form of a transposed conv (wins once a phase's K = Ci .. 4 Ci is long: the lip encoder's stride-2 convs)."""
     Co = wp.shape[0]
-    if geom["ctrans"] and res is None and Co <= 32:
+    if geom["ctrans"] and res is None and (Co <= 32 or phases):
         # measured: the four parity GEMMs win only while the tile is narrow (Co = 32: 499 vs 542 us at
         # full resolution); at Co >= 64 the K of a phase is too short and one 9-tap GEMM is faster
         return conv_gemm_transposed(x, wp, bias, out, geom)
@@ -422,7 +423,7 @@ def _pack_dgrad(w, kind, dt):
     return _pp("pdup", w, (0, 2, 3, 1), dt).view(w.shape[0], -1)                    # up: [Ci][tap][Co]
 
 
-def _conv_backward(kind, x, w, dy, need_dx, tile=True):
+def _conv_backward(kind, x, w, dy, need_dx, tile=True, phases=False):
     """dy: gradient of the raw conv output [B,Fo,To,Co]. Returns dx, dw (param layout, fp32).  tile=False keeps a
     stride-1 conv off the 16x16-pixel tile kernels (small images: Conv3x3)."""
     B, Fi, Ti, Ci = x.shape
@@ -454,7 +455,7 @@ def _conv_backward(kind, x, w, dy, need_dx, tile=True):
     dx = None
     if need_dx:
         dx = torch.empty_like(x)
-        conv_gemm(dy, _pack_dgrad(w, kind, x.dtype), None, dx, gd)
+        conv_gemm(dy, _pack_dgrad(w, kind, x.dtype), None, dx, gd, phases=phases)
     return dx, dw.contiguous()
 
 
@@ -525,21 +526,23 @@ class Conv3x3(torch.autograd.Function):
     (ours: 324-365 vs 285-306 us)."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, stride=1):
         xc = x.permute(0, 2, 3, 1)
         if not xc.is_contiguous():
             xc = xc.contiguous()
         B, Fi, Ti, Ci = xc.shape
         Co = w.shape[0]
-        tile = Fi * Ti >= 400 and _fast3(xc, Co)
-        wp = _pack_fwd(w, "s1", xc.dtype)
+        kind = "s1" if stride == 1 else "down"              # stride 2: implicit GEMM forward, four-parity data gradient
+        tile = kind == "s1" and Fi * Ti >= 400 and _fast3(xc, Co)
+        wp = _pack_fwd(w, kind, xc.dtype)
         if tile:
             y = conv3x3_s1(xc, wp, None)[0]
         else:
-            y = _empty((B, Fi, Ti, Co), xc.dtype, xc.device)
-            conv_gemm(xc, wp, None, y, _conv_geoms("s1", B, Fi, Ti, Ci, Co)[2])
+            Fo, To, gf, _, _ = _conv_geoms(kind, B, Fi, Ti, Ci, Co)
+            y = _empty((B, Fo, To, Co), xc.dtype, xc.device)
+            conv_gemm(xc, wp, None, y, gf)
         ctx.save_for_backward(xc, w)
-        ctx.tile = tile
+        ctx.tile, ctx.kind = tile, kind
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -548,8 +551,55 @@ class Conv3x3(torch.autograd.Function):
         dyc = dy.permute(0, 2, 3, 1)
         if not dyc.is_contiguous():
             dyc = dyc.contiguous()
-        dx, dw = _conv_backward("s1", xc, w, dyc, ctx.needs_input_grad[0], tile=ctx.tile)
-        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dw
+        dx, dw = _conv_backward(ctx.kind, xc, w, dyc, ctx.needs_input_grad[0], tile=ctx.tile, phases=True)
+        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dw, None
+
+
+class Conv1x1s2(torch.autograd.Function):
+    """Bias-free 1x1 stride-2 convolution (the downsample branch of a ResNet block, VideoEncoders/resnet.py:31-33
+    downsample_basic_block) on channels-last frames: x [N, Ci, H, W] (channels-last memory), w [Co, Ci, 1, 1].
+    Forward and weight gradient gather every second pixel through dtt_gemm's general conv geometry (kernel width 1,
+    no padding); the data gradient is a plain GEMM scattered to the even pixels of a zeroed tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xc = x.permute(0, 2, 3, 1)
+        if not xc.is_contiguous():
+            xc = xc.contiguous()
+        B, Fi, Ti, Ci = xc.shape
+        Co = w.shape[0]
+        Fo, To = (Fi - 1) // 2 + 1, (Ti - 1) // 2 + 1
+        geom = dict(cB=B, cFi=Fi, cTi=Ti, cCi=Ci, cFo=Fo, cTo=To, cstride=2, ctrans=0, cKW=1, cPadF=0, cPadT=0)
+        wp = w.view(Co, Ci).to(xc.dtype)
+        y = _empty((B, Fo, To, Co), xc.dtype, xc.device)
+        gemm_raw(A=xc, B=wp, C=y, M=B * Fo * To, N=Co, K=Ci, a_ms=0, a_ks=1, b_ks=1, b_ns=Ci, c_ms=Co, c_ns=1, dtype=_dt(xc),
+                 a_mode=1, **geom)
+        ctx.save_for_backward(xc, w)
+        ctx.geom = geom
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, w = ctx.saved_tensors
+        g = ctx.geom
+        B, Fi, Ti, Ci = xc.shape
+        Co = w.shape[0]
+        dyc = dy.permute(0, 2, 3, 1)
+        if not dyc.is_contiguous():
+            dyc = dyc.contiguous()
+        P = B * g["cFo"] * g["cTo"]
+        dwp = _zeros_f32((Co, Ci), xc.device)
+        gemm_raw(A=dyc, B=xc, C=dwp, M=Co, N=Ci, K=P, splitk=_splitk(Co, Ci, P), a_ms=1, a_ks=Co, b_ks=Ci, b_ns=1, c_ms=Ci,
+                 c_ns=1, dtype=_dt(xc), atomic=1, out_f32=1, b_mode=1, **g)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            t = _empty((P, Ci), xc.dtype, xc.device)
+            wq = w.view(Co, Ci).to(xc.dtype)                         # [Co][Ci]: B(k = co, n = ci) row-contiguous
+            gemm_raw(A=dyc, B=wq, C=t, M=P, N=Ci, K=Co, a_ms=Co, a_ks=1, b_ks=Ci, b_ns=1, c_ms=Ci, c_ns=1, dtype=_dt(xc))
+            dx = torch.zeros_like(xc)
+            dx[:, ::2, ::2] = t.view(B, g["cFo"], g["cTo"], Ci)
+            dx = dx.permute(0, 3, 1, 2)
+        return dx, dwp.view(Co, Ci, 1, 1)
 
 
 class FrontConv(torch.autograd.Function):

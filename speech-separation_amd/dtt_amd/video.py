@@ -1,8 +1,11 @@
 """Lip-ROI video encoders.  Same parameter names as the
 reference and NO network fetch (the reference downloads a checkpoint with gdown in __init__,
-resnet_video_encoder.py:46-60).  ResNet-18 encoder: BatchNorm + Swish (+ residual), the max pool and the stride-1
-3x3 convolutions of the trunk run on the HIP kernels (ops.BatchNormAct, ops.MaxPool3x3s2, ops.Conv3x3); the front-end
-convolution, the three stride-2 3x3 and the three 1x1 convolutions are MIOpen's.  ShuffleNetV2 encoder: stock modules.
+resnet_video_encoder.py:46-60).  ResNet-18 encoder: every stage runs on the HIP kernels -- the front-end convolution
+(dtt_stack_frames + ops.FrontConv), BatchNorm + Swish (+ residual) (ops.BatchNormAct), the max pool
+(ops.MaxPool3x3s2), the trunk's 3x3 convolutions of either stride (ops.Conv3x3) and its 1x1 stride-2 downsample
+convolutions (ops.Conv1x1s2): no library convolution is left in the step.  Switches for A/B runs:
+DTT_VIDEO_OWN_CONV=0 (all convolutions on MIOpen), DTT_VIDEO_FRONT_CONV=0, DTT_VIDEO_S2_CONV=0 (only those).
+ShuffleNetV2 encoder (FiLM model): stock modules.
 
 Reference: src/model/VideoEncoders/{resnet,resnet_video_encoder}.py.
 """
@@ -21,14 +24,23 @@ _OWN_CONV = os.environ.get("DTT_VIDEO_OWN_CONV", "1") == "1"      # 0: every lip
 _OWN_FRONT = os.environ.get("DTT_VIDEO_FRONT_CONV", "1") == "1"   # 0: only the front-end convolution on MIOpen
 
 
+_OWN_S2 = os.environ.get("DTT_VIDEO_S2_CONV", "1") == "1"         # 0: the trunk's stride-2 3x3 and 1x1 convolutions on MIOpen
+
+
 def _conv3x3(conv, x):
-    """The trunk's stride-1 3x3 convolutions on the HIP kernels (ops.Conv3x3); stride-2 and 1x1 ones on MIOpen."""
-    if (_OWN_CONV and conv.stride == (1, 1) and conv.kernel_size == (3, 3) and conv.in_channels % 32 == 0
-            and conv.out_channels % 32 == 0 and x.dtype in (torch.bfloat16, torch.float32)):
-        from .ops import Conv3x3
+    """The trunk's convolutions on the HIP kernels: 3x3 stride 1 / 2 (ops.Conv3x3) and the 1x1 stride-2 downsample
+    (ops.Conv1x1s2); anything else on MIOpen."""
+    ok = (_OWN_CONV and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.bias is None
+          and x.dtype in (torch.bfloat16, torch.float32))
+    k, st, pd = conv.kernel_size, conv.stride, conv.padding
+    if ok and ((k == (3, 3) and pd == (1, 1) and (st == (1, 1) or (st == (2, 2) and _OWN_S2)))
+               or (k == (1, 1) and pd == (0, 0) and st == (2, 2) and _OWN_S2)):
+        from .ops import Conv3x3, Conv1x1s2
         if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_dtype("cuda"))
-        return Conv3x3.apply(x, conv.weight)
+        if k == (1, 1):
+            return Conv1x1s2.apply(x, conv.weight)
+        return Conv3x3.apply(x, conv.weight, st[0])
     return conv(x)
 
 
@@ -79,7 +91,7 @@ class BasicBlock(nn.Module):
         # BatchNorm + Swish (+ residual) as ONE HIP pass forward and two backward (ops.BatchNormAct); the stride-1
         # 3x3 convolutions on our kernels, the stride-2 / 1x1 ones on MIOpen
         from .ops import batch_norm_act
-        r = x if self.downsample is None else batch_norm_act(self.downsample[0](x), self.downsample[1], 0)
+        r = x if self.downsample is None else batch_norm_act(_conv3x3(self.downsample[0], x), self.downsample[1], 0)
         y = batch_norm_act(_conv3x3(self.conv1, x), self.bn1, 1)
         return batch_norm_act(_conv3x3(self.conv2, y), self.bn2, 1, res=r)
 

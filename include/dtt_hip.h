@@ -330,6 +330,16 @@ int dtt_bn_frozen_stats(const float* running_mean, const float* running_var, flo
 int dtt_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int dtype, void* stream);
 int dtt_maxpool3x3s2_bwd(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C, int dtype,
                          void* stream);
+/* BatchNorm + activation + the 3x3 / stride-2 / pad-1 max pool in one pass each way (lip front end,
+ * resnet_video_encoder.py:38-44: BatchNorm3d -> Swish -> MaxPool3d((1,3,3),(1,2,2),(0,1,1))): forward from given
+ * statistics to the pooled tensor y [N][Ho][Wo][C] and its argmax bytes; backward from the pooled gradient to the
+ * gradient of the BatchNorm input and dgb = {dgamma, dbeta} (scratch as dtt_bn_act_bwd).  The pre-pool tensor and its
+ * gradient are never materialised. */
+int dtt_bn_act_pool_fwd(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
+                        unsigned char* idx, int N, int H, int W, int C, int act, int dtype, void* stream);
+int dtt_bn_act_pool_bwd(const void* x, const void* dyp, const unsigned char* idx, const float* stats, const float* gamma,
+                        const float* beta, float* partial, float* sums, float* dgb, void* dx, int N, int H, int W, int C,
+                        int act, int training, int dtype, void* stream);
 
 /* Gradient clip + AdamW over a table of fp32 tensors in two launches (the step after the hot path:
  * torch.optim.AdamW of train.yaml:20-23 after clip_grad_norm_ of base_trainer.py:478-490, train.yaml:59).

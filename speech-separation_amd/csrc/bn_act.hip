@@ -179,11 +179,54 @@ __global__ __launch_bounds__(32 * FG) void bn_stats_finalize(const float* __rest
 }
 
 // pass 1: partial[chunk][C][2] = {sum da, sum da * xhat},  da = dz * act'(gamma * xhat + beta (+ res))
-template <typename T, int ACT>
+// POOL: dz is not given per pixel but as the gradient of a 3x3 / stride-2 / pad-1 max pool of the activation output
+// (dz = pooled gradient [N][Ho][Wo][C], idx = the pool's argmax bytes): the pixel's gradient is gathered from the <= 4
+// windows that cover it (pool_grad), so the pre-pool gradient tensor is never materialised.
+struct PoolGeom { const unsigned char* idx; int H, W, Ho, Wo; };
+template <typename T>
+__device__ __forceinline__ Vec16<T> pool_grad(const T* __restrict__ dyp, const PoolGeom& g, int q, int C, int cq, bool ok) {
+    constexpr int EPT = Vec16<T>::N;
+    const int w = q % g.W, r = q / g.W, h = r % g.H, n = r / g.H;
+    // The windows that cover row h: ho0 = (h + 1) / 2 at kh0 = h + 1 - 2 ho0 (0 for odd h, 1 for even h) and, for odd
+    // h only, ho0 - 1 at kh0 + 2.  Columns alike.  All four candidates are loaded unconditionally (a dead candidate
+    // reads the tensor's first element and is masked): four independent loads in flight, no branch.
+    const int ho0 = (h + 1) >> 1, kh0 = h + 1 - 2 * ho0, wo0 = (w + 1) >> 1, kw0 = w + 1 - 2 * wo0;
+    Vec16<T> gv[4];
+    unsigned long long ib[4];
+    bool live[4];
+    unsigned char want[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ho = ho0 - a, wo = wo0 - b, kh = kh0 + 2 * a, kw = kw0 + 2 * b, k = a * 2 + b;
+            live[k] = ok && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo && kh <= 2 && kw <= 2;
+            want[k] = (unsigned char)(kh * 3 + kw);
+            const int64_t ob = live[k] ? (((int64_t)n * g.Ho + ho) * g.Wo + wo) * C + cq * EPT : 0;
+            gv[k] = ld16<T>(dyp + ob);
+            if (EPT == 8) ib[k] = *reinterpret_cast<const unsigned long long*>(g.idx + ob);
+            else ib[k] = *reinterpret_cast<const unsigned int*>(g.idx + ob);
+        }
+    float acc[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            acc[e] += (live[k] && (unsigned char)(ib[k] >> (8 * e)) == want[k]) ? gv[k].get(e) : 0.f;
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) o.set(e, acc[e]);
+    return o;
+}
+
+template <typename T, int ACT, bool POOL = false>
 __global__ __launch_bounds__(NT) void bn_act_bwd_partial(const T* __restrict__ x, const T* __restrict__ res,
                                                          const T* __restrict__ dz, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ partial, int P, int C, int chunk) {
+                                                         float* __restrict__ partial, int P, int C, int chunk,
+                                                         PoolGeom pg = PoolGeom{}) {
     constexpr int EPT = Vec16<T>::N, U = 4;
     extern __shared__ float sm[];
     float* red = sm;
@@ -208,7 +251,8 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_partial(const T* __restrict__ x
             for (int u = 0; u < U; ++u) {
                 const int q = p + u * ppi;
                 v[u] = ld16_pred<T>(xb + (int64_t)q * C, xb, q < p1);
-                g[u] = ld16_pred<T>(gb + (int64_t)q * C, gb, q < p1);      // zero beyond the chunk: contributes nothing
+                if constexpr (POOL) g[u] = pool_grad<T>(dz, pg, q, C, cq, q < p1);
+                else g[u] = ld16_pred<T>(gb + (int64_t)q * C, gb, q < p1);      // zero beyond the chunk: contributes nothing
                 if (rb) r[u] = ld16_pred<T>(rb + (int64_t)q * C, rb, q < p1);
             }
 #pragma unroll
@@ -253,12 +297,13 @@ __global__ __launch_bounds__(32 * FG) void bn_bwd_finalize(const float* __restri
 
 // pass 2: dx = gamma * rstd * (da - S1/n - xhat * S2/n)  (training) or gamma * rstd * da (frozen statistics);
 // dres = da
-template <typename T, int ACT>
+template <typename T, int ACT, bool POOL = false>
 __global__ __launch_bounds__(NT) void bn_act_bwd_apply(const T* __restrict__ x, const T* __restrict__ res,
                                                        const T* __restrict__ dz, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ sums, T* __restrict__ dx,
-                                                       T* __restrict__ dres, int P, int C, int chunk, int training) {
+                                                       T* __restrict__ dres, int P, int C, int chunk, int training,
+                                                       PoolGeom pg = PoolGeom{}) {
     constexpr int EPT = Vec16<T>::N, U = 4;
     const int cpp = C / EPT, ppi = NT / cpp;
     const int tid = threadIdx.x, pl = tid / cpp, cq = tid % cpp;
@@ -283,7 +328,8 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply(const T* __restrict__ x, 
         for (int u = 0; u < U; ++u) {
             const int q = p + u * ppi;
             v[u] = ld16_pred<T>(xb + (int64_t)q * C, xb, q < p1);
-            g[u] = ld16_pred<T>(gb + (int64_t)q * C, gb, q < p1);
+            if constexpr (POOL) g[u] = pool_grad<T>(dz, pg, q, C, cq, q < p1);
+            else g[u] = ld16_pred<T>(gb + (int64_t)q * C, gb, q < p1);
             if (rb) r[u] = ld16_pred<T>(rb + (int64_t)q * C, rb, q < p1);
         }
 #pragma unroll
@@ -329,6 +375,60 @@ __global__ void bn_frozen_stats_kernel(const float* __restrict__ rmean, const fl
     if (c >= C) return;
     stats[c * 2] = rmean[c];
     stats[c * 2 + 1] = rsqrtf(rvar[c] + eps);
+}
+
+// act(batch_norm(x)) followed by the 3x3 / stride-2 / pad-1 max pool in one pass: one lane = one pooled pixel x one
+// 16-byte channel chunk; the nine activation values are recomputed from x (2.25 reads per input element, served by
+// L1 / L2), rounded to T as the unfused pair would store them, first maximum in (kh, kw) scan order.  The 400 MB
+// pre-pool tensor of the lip front end is neither written nor read.
+template <typename T, int ACT>
+__global__ __launch_bounds__(NT) void bn_act_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             T* __restrict__ y, unsigned char* __restrict__ idx, int N, int H,
+                                                             int W, int C, int Ho, int Wo) {
+    constexpr int EPT = Vec16<T>::N;
+    const int cpp = C / EPT;
+    const int64_t total = (int64_t)N * Ho * Wo * cpp;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int cq = (int)(i % cpp);
+        int64_t q = i / cpp;
+        const int wo = (int)(q % Wo); q /= Wo;
+        const int ho = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        float sc[EPT], sh[EPT], best[EPT];
+        unsigned char bi[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int c = cq * EPT + e;
+            const float mean = stats[c * 2], rstd = stats[c * 2 + 1];
+            sc[e] = gamma[c] * rstd;
+            sh[e] = beta[c] - mean * sc[e];
+            best[e] = -INFINITY; bi[e] = 4;
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int h = 2 * ho - 1 + kh, w = 2 * wo - 1 + kw;
+                if (h < 0 || h >= H || w < 0 || w >= W) continue;
+                const Vec16<T> v = ld16<T>(x + (((int64_t)n * H + h) * W + w) * C + cq * EPT);
+                Vec16<T> zr;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) zr.set(e, act_f<ACT>(v.get(e) * sc[e] + sh[e]));
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const float f = zr.get(e);
+                    if (f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(kh * 3 + kw); }
+                }
+            }
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) o.set(e, best[e]);
+        const int64_t ob = (((int64_t)n * Ho + ho) * Wo + wo) * C + cq * EPT;
+        st16<T>(y + ob, o);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) idx[ob + e] = bi[e];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -479,6 +579,50 @@ extern "C" int dtt_bn_act_bwd(const void* x, const void* res, const void* dz, co
 #undef BP
     hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 31) / 32), dim3(32 * FG), 0, ST, partial, sums, dgb, C, nch);
 #define BA(TT, A) hipLaunchKernelGGL((bn_act_bwd_apply<TT, A>), dim3(nch), dim3(NT), 0, ST, (const TT*)x, (const TT*)res, (const TT*)dz, stats, gamma, beta, sums, (TT*)dx, (TT*)dres, P, C, chunk, training)
+    if (dtype) { if (act == 1) BA(bf16, 1); else if (act == 2) BA(bf16, 2); else BA(bf16, 0); }
+    else { if (act == 1) BA(float, 1); else if (act == 2) BA(float, 2); else BA(float, 0); }
+#undef BA
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+// BatchNorm + activation + 3x3 / stride-2 / pad-1 max pool fused (the lip front end, resnet_video_encoder.py:38-44):
+// forward from given statistics (dtt_bn_stats / dtt_bn_frozen_stats) -> pooled y [N][Ho][Wo][C] + argmax bytes; backward
+// from the pooled gradient: dx (gradient of the BatchNorm input) and dgb = {dgamma, dbeta}, same scratch as dtt_bn_act_bwd.
+extern "C" int dtt_bn_act_pool_fwd(const void* x, const float* stats, const float* gamma, const float* beta, void* y,
+                                   unsigned char* idx, int N, int H, int W, int C, int act, int dtype, void* stream) {
+    const int ept = dtype ? 8 : 4;
+    DTT_CHECK(x && stats && gamma && beta && y && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % ept == 0 && act >= 0 && act <= 2,
+              "dtt_bn_act_pool_fwd: bad arguments (C=%d)", C);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / ept);
+    const int grid = (int)std::min<int64_t>((total + NT - 1) / NT, 65536);
+#define PF(TT, A) hipLaunchKernelGGL((bn_act_pool_fwd_kernel<TT, A>), dim3(grid), dim3(NT), 0, ST, (const TT*)x, stats, gamma, beta, (TT*)y, idx, N, H, W, C, Ho, Wo)
+    if (dtype) { if (act == 1) PF(bf16, 1); else if (act == 2) PF(bf16, 2); else PF(bf16, 0); }
+    else { if (act == 1) PF(float, 1); else if (act == 2) PF(float, 2); else PF(float, 0); }
+#undef PF
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_bn_act_pool_bwd(const void* x, const void* dyp, const unsigned char* idx, const float* stats,
+                                   const float* gamma, const float* beta, float* partial, float* sums, float* dgb, void* dx,
+                                   int N, int H, int W, int C, int act, int training, int dtype, void* stream) {
+    DTT_CHECK(N > 0 && H > 0 && W > 0 && (int64_t)N * H * W < (1LL << 31), "dtt_bn_act_pool_bwd: bad shape");
+    const int P = N * H * W;
+    if (int rc = bn_check(P, C, dtype, "dtt_bn_act_pool_bwd")) return rc;
+    DTT_CHECK(x && dyp && idx && stats && gamma && beta && partial && sums && dgb && dx && act >= 0 && act <= 2,
+              "dtt_bn_act_pool_bwd: bad arguments");
+    const int chunk = bn_chunk(P), nch = (P + chunk - 1) / chunk;
+    const int ept = dtype ? 8 : 4;
+    const size_t sm = (size_t)(NT * ept + C) * sizeof(float);
+    const PoolGeom pg{idx, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+#define BP(TT, A) hipLaunchKernelGGL((bn_act_bwd_partial<TT, A, true>), dim3(nch), dim3(NT), sm, ST, (const TT*)x, (const TT*)nullptr, (const TT*)dyp, stats, gamma, beta, partial, P, C, chunk, pg)
+    if (dtype) { if (act == 1) BP(bf16, 1); else if (act == 2) BP(bf16, 2); else BP(bf16, 0); }
+    else { if (act == 1) BP(float, 1); else if (act == 2) BP(float, 2); else BP(float, 0); }
+#undef BP
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 31) / 32), dim3(32 * FG), 0, ST, partial, sums, dgb, C, nch);
+#define BA(TT, A) hipLaunchKernelGGL((bn_act_bwd_apply<TT, A, true>), dim3(nch), dim3(NT), 0, ST, (const TT*)x, (const TT*)nullptr, (const TT*)dyp, stats, gamma, beta, sums, (TT*)dx, (TT*)nullptr, P, C, chunk, training, pg)
     if (dtype) { if (act == 1) BA(bf16, 1); else if (act == 2) BA(bf16, 2); else BA(bf16, 0); }
     else { if (act == 1) BA(float, 1); else if (act == 2) BA(float, 2); else BA(float, 0); }
 #undef BA

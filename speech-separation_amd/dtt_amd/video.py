@@ -24,6 +24,7 @@ _OWN_CONV = os.environ.get("DTT_VIDEO_OWN_CONV", "1") == "1"      # 0: every lip
 _OWN_FRONT = os.environ.get("DTT_VIDEO_FRONT_CONV", "1") == "1"   # 0: only the front-end convolution on MIOpen
 
 
+_FUSED_POOL = os.environ.get("DTT_VIDEO_FUSED_POOL", "1") == "1"   # 0: front-end BatchNorm + Swish and max pool as two ops
 _OWN_S2 = os.environ.get("DTT_VIDEO_S2_CONV", "1") == "1"         # 0: the trunk's stride-2 3x3 and 1x1 convolutions on MIOpen
 
 
@@ -151,7 +152,12 @@ class VideoEncoder(nn.Module):
         its output is born as [frames, 64, 44, 44] in channels-last memory: no im2col of a 3-d volume, no layout
         change towards the 2-d trunk.  BatchNorm3d's statistics over (N, D, H, W) are BatchNorm2d's over
         (N * D, H, W); BN + Swish and the (1,3,3) max pool run on the fused kernels."""
-        from .ops import batch_norm_act, MaxPool3x3s2
+        from .ops import batch_norm_act, batch_norm_act_pool, MaxPool3x3s2
+
+        def bn_pool(y):
+            if _FUSED_POOL:
+                return batch_norm_act_pool(y, bn, 1)
+            return MaxPool3x3s2.apply(batch_norm_act(y, bn, 1))
         conv, bn = self.frontend3D[0], self.frontend3D[1]
         Bp, _, T, H, W = x.shape
         kt = conv.kernel_size[0]
@@ -172,8 +178,7 @@ class VideoEncoder(nn.Module):
                                                  1 if odt == torch.bfloat16 else 0, ops.stream_ptr()), "dtt_stack_frames")
             if own:
                 y = ops.FrontConv.apply(buf, conv.weight, H, W).permute(0, 3, 1, 2)   # NCHW view of channels-last memory
-                y = batch_norm_act(y, bn, 1)
-                return MaxPool3x3s2.apply(y), T
+                return bn_pool(y), T
             x5 = buf.permute(0, 3, 1, 2)                                          # NCHW view of channels-last memory
         else:
             xp = nn.functional.pad(x[:, 0], (0, 0, 0, 0, kt // 2, kt // 2))        # [B', T + 4, H, W]
@@ -184,8 +189,7 @@ class VideoEncoder(nn.Module):
         if cpad:
             w2 = nn.functional.pad(w2, (0, 0, 0, 0, 0, cpad))
         y = nn.functional.conv2d(x5, w2, None, stride=conv.stride[1:], padding=conv.padding[1:])
-        y = batch_norm_act(y, bn, 1)
-        return MaxPool3x3s2.apply(y), T
+        return bn_pool(y), T
 
     def forward(self, x):
         B, N, T, H, W = x.shape

@@ -406,3 +406,45 @@ def test_front_conv_against_conv3d(dt, tol):
     y.backward(gy.to(DEV))
     ref.backward(gy.double().reshape(N, T, H // 2, W // 2, Co).permute(0, 4, 1, 2, 3))
     assert rel_err(wd.grad.cpu(), wr.grad) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_batchnorm_swish_maxpool_against_the_two_ops(dt, train):
+    """ops.BatchNormActPool (BatchNorm + Swish + 3x3 / stride-2 max pool in one pass each way) against
+    ops.BatchNormAct followed by ops.MaxPool3x3s2 on odd and even frame sizes: pooled output bit-exact (the fused
+    kernel rounds the activation to the tensor's dtype before comparing, as the pair stores it), input / gamma / beta
+    gradients, running statistics."""
+    from dtt_amd import ops, video
+    g = torch.Generator().manual_seed(9)
+    for (N, Cc, H, W) in [(5, 64, 12, 10), (3, 32, 11, 13)]:
+        bn = video.BatchNorm2d(Cc).to(DEV)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+        state0 = {k: v.clone() for k, v in bn.state_dict().items()}
+        x0 = (torch.randn(N, Cc, H, W, generator=g) * 1.5 + 0.3).to(DEV).to(dt).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(N, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1, generator=g).to(DEV).to(dt)
+        outs = []
+        try:
+            for fused in (0, 1, 2):                        # the pair; fused forward; fused forward and backward
+                bn.load_state_dict(state0)
+                bn.train(train)
+                bn.zero_grad()
+                ops._POOL_BWD_FUSED = fused == 2
+                x = x0.clone().requires_grad_(True)
+                y = ops.batch_norm_act_pool(x, bn, 1) if fused else ops.MaxPool3x3s2.apply(ops.batch_norm_act(x, bn, 1))
+                y.backward(gy)
+                outs.append((y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                             bn.running_mean.clone(), bn.running_var.clone()))
+        finally:
+            ops._POOL_BWD_FUSED = False
+        a = outs[0]
+        tol = 1e-5 if dt == torch.float32 else 2e-2
+        for b in outs[1:]:
+            assert torch.equal(a[0], b[0])
+            assert rel_err(b[1].float(), a[1].float()) < tol
+            assert rel_err(b[2], a[2]) < tol and rel_err(b[3], a[3]) < tol
+            assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+

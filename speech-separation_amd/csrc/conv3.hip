@@ -14,6 +14,12 @@
 namespace {
 
 constexpr int TH = 16, TW = 16, PH = TH + 2, PW = TW + 2, KC = 32;
+// Patch rows start on multiples of 256 bytes (= all 64 LDS banks).  An A-fragment read (ds_read_b128) takes, per 16-lane
+// group, tile columns 0-3 and 12-15 of one patch row and 4-11 of the next: with 80-byte (144-byte fp32) pixels the sixteen
+// columns of one row fall on sixteen different 4-bank slots, and with the next row a whole number of bank rounds further
+// its columns keep theirs -- no conflict.  At the natural pitch of 18 pixels two of the eight collided (35 % of the
+// LDS-array cycles of conv3x3_s1_kernel were bank-conflict cycles, profiles/r02z_pmc_sq_lds_mfma.txt).
+template <typename T, int LDC> struct PatchPitch { static constexpr int ROWP = (PW * LDC * (int)sizeof(T) + 255) / 256 * 256 / (int)sizeof(T); };
 
 struct Conv3P {
     const void* x; const void* wp; const float* bias; void* y; const void* res; float* partial;
@@ -137,8 +143,9 @@ template <typename T, int TN>
 __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
     constexpr int EPT = MM<T>::EPT, LDC = KC + MM<T>::PAD, BN = 32 * TN, CPR = KC / EPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* patch = reinterpret_cast<T*>(smem);                  // [PH*PW][LDC]
-    T* wl = patch + PH * PW * LDC;                          // [9*BN][LDC]
+    constexpr int ROWP = PatchPitch<T, LDC>::ROWP;          // elements between patch rows (256-byte multiples)
+    T* patch = reinterpret_cast<T*>(smem);                  // [PH][ROWP >= PW*LDC]
+    T* wl = patch + PH * ROWP;                              // [9*BN][LDC]
 
     const int ntile_n = p.Co / BN;
     int bid = blockIdx.x;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
 #pragma unroll
         for (int it = 0; it < NP; ++it) {
             const int idx = tid + it * 256;
-            if (idx < NPC) st16<T>(patch + (idx / CPR) * LDC + (idx % CPR) * EPT, pre_p[it]);
+            if (idx < NPC) { const int pix = idx / CPR; st16<T>(patch + (pix / PW) * ROWP + (pix % PW) * LDC + (idx % CPR) * EPT, pre_p[it]); }
         }
 #pragma unroll
         for (int it = 0; it < NW; ++it) {
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     int prow = wave * 4 + a * 2 + (lr >> 4) + kh, pcol = (lr & 15) + kw;
-                    af[a] = MM<T>::ldfrag(patch + (prow * PW + pcol) * LDC + kofs);
+                    af[a] = MM<T>::ldfrag(patch + prow * ROWP + pcol * LDC + kofs);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[j] = MM<T>::ldfrag(wl + (tap * BN + j * 32 + lr) * LDC + kofs);
@@ -230,8 +237,8 @@ __global__ __launch_bounds__(256) void conv3x3_s1_kernel(Conv3P p) {
 // patch is prefetched into registers while the current one is in the MFMAs.
 template <bool RES>
 __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles_per_wg) {
-    constexpr int LDC = 40, NPC = PH * PW * 4, NIT = (NPC + 255) / 256, SW = 36;
-    __shared__ __attribute__((aligned(16))) bf16 patch[PH * PW * LDC];
+    constexpr int LDC = 40, NPC = PH * PW * 4, NIT = (NPC + 255) / 256, SW = 36, ROWP = PatchPitch<bf16, LDC>::ROWP;
+    __shared__ __attribute__((aligned(256))) bf16 patch[PH * ROWP];
     __shared__ __attribute__((aligned(16))) float stage_all[4 * 64 * SW];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const bf16* wp = reinterpret_cast<const bf16*>(p.wp);
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256;
-            if (idx < NPC) st16<bf16>(patch + (idx >> 2) * LDC + (idx & 3) * 8, pre[it]);
+            if (idx < NPC) { const int pix = idx >> 2; st16<bf16>(patch + (pix / PW) * ROWP + (pix % PW) * LDC + (idx & 3) * 8, pre[it]); }
         }
     };
     park();
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const int prow = wave * 4 + a * 2 + (lr >> 4) + kh, pcol = (lr & 15) + kw;
-                    const s16x8_t af = MM<bf16>::ldfrag(patch + (prow * PW + pcol) * LDC + s * 16 + lh * 8);
+                    const s16x8_t af = MM<bf16>::ldfrag(patch + prow * ROWP + pcol * LDC + s * 16 + lh * 8);
                     MM<bf16>::mma(af, wf[tap][s], acc[a][0]);
                 }
             }
@@ -674,7 +681,7 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
     }
     const int tn = (Co % 64 == 0) ? 2 : 1, bn = 32 * tn;
     const int ldc = KC + (dtype ? 8 : 4), es = dtype ? 2 : 4;
-    size_t sm = (size_t)(PH * PW + 9 * bn) * ldc * es;
+    size_t sm = (size_t)PH * (((size_t)PW * ldc * es + 255) / 256 * 256) + (size_t)9 * bn * ldc * es;
     sm = max(sm, (size_t)4 * 64 * (bn + 4) * 4);             // output staging overlays the operands
     dim3 grid(p.tiles_f * p.tiles_t * (Co / bn), B);
 #define LAUNCH(TT, TN_) do { auto k = conv3x3_s1_kernel<TT, TN_>; \

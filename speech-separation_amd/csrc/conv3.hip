@@ -679,7 +679,13 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
         DTT_LAUNCH_CHECK();
         return 0;
     }
-    const int tn = (Co % 64 == 0) ? 2 : 1, bn = 32 * tn;
+    // 64 output channels per workgroup (one LDS fragment read per MFMA, two workgroups per CU) unless that leaves
+    // the launch with fewer than ~4.5 workgroups per CU: then 32 channels (three per CU, twice the workgroups) fills
+    // the last round better -- B = 16 at 64 x 257 x 63 / 128 x 129 x 32 / 256 x 65 x 16: 42.9 -> 41.6, 38.9 -> 37.0,
+    // 41.0 -> 38.1 us; at B = 64 (4352 workgroups) the 64-channel form stays 1-6 % ahead.
+    int tn = (Co % 64 == 0) ? 2 : 1;
+    if (tn == 2 && dtype == 1 && (int64_t)p.tiles_f * p.tiles_t * (Co / 64) * B <= 1152) tn = 1;
+    const int bn = 32 * tn;
     const int ldc = KC + (dtype ? 8 : 4), es = dtype ? 2 : 4;
     size_t sm = (size_t)PH * (((size_t)PW * ldc * es + 255) / 256 * 256) + (size_t)9 * bn * ldc * es;
     sm = max(sm, (size_t)4 * 64 * (bn + 4) * 4);             // output staging overlays the operands

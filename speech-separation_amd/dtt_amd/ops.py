@@ -890,6 +890,17 @@ class DualPathRNN(torch.autograd.Function):
         # recurrent backward
         dG = _empty((R, 2, 4 * H), dt, dev)
         dbias = None
+        # The NON-deep form of lstm_rs_bwd_kernel (clusters with < 3 tiles: the frequency-axis pass) is not used by
+        # default (DESIGN finding 34): inside a replayed HIP graph, once the host had synchronised with the stream, it
+        # returned wrong gate gradients from the second replay on (the loss stops falling, the gradient norm jumps
+        # from ~15 to ~1e4; eager launches, the forward kernels and the deep form on the time axis are not affected,
+        # and the parity tests pass).  Until that is understood the frequency-axis backward of an rs forward runs on
+        # the LDS-cluster kernel, which reads the same saved layout.  DTT_LSTM_BWD = rs_time | cluster | rs | rs_freq.
+        bsel = os.environ.get("DTT_LSTM_BWD", "rs_time")
+        if rs and (bsel == "cluster" or (bsel == "rs_time" and along_f) or (bsel == "rs_freq" and not along_f)):
+            geom_c = _cluster_geometry(nslab * heads, H, d)
+            if geom_c is not None:
+                rs, geom = False, geom_c
         if rs:
             N = nslab * heads
             NT = (N + 31) // 32

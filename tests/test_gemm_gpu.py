@@ -234,9 +234,11 @@ def test_gemm_row_shift(dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Ci,Co,Fq,T", [(32, 32, 33, 20), (64, 64, 17, 13), (32, 96, 16, 16), (128, 64, 9, 35)])
+@pytest.mark.parametrize("Ci,Co,Fq,T", [(32, 32, 33, 20), (64, 64, 17, 13), (32, 96, 16, 16), (128, 64, 9, 35),
+                                          (64, 64, 22, 22), (64, 128, 38, 17), (128, 128, 65, 16)])
 def test_conv3x3_dedicated_kernels(dt, Ci, Co, Fq, T):
-    """dtt_conv3x3_s1 (+ fused residual and InstanceNorm statistics) and dtt_conv3x3_wgrad."""
+    """dtt_conv3x3_s1 (+ fused residual and InstanceNorm statistics) and dtt_conv3x3_wgrad.  The row counts cover
+    every length of the last tile row's walk: 1 valid row (17, 33, 65), 6 (22, 38), 9 and 16."""
     from dtt_amd import ops
     g = torch.Generator().manual_seed(Ci * 3 + Co + Fq)
     dev = "cuda"

@@ -126,3 +126,36 @@ def test_pack_plan_matches_plain_steps():
     assert abs(l0 - l1) <= 1e-6 * abs(l0) and abs(l0 - l2) <= 1e-6 * abs(l0) and abs(l3 - l4) <= 1e-6 * abs(l3)
     assert abs(l3 - l0) > 1e-6 * abs(l0)
     assert close(g0, g1) and close(g0, g2) and close(g4, g3)
+
+
+def test_bench_step_keeps_learning_after_a_host_sync():
+    """The default bench workload (cfg4: x-attn 60M, B = 16, bf16, H = 512 register-stationary LSTM kernels) as a
+    replayed HIP graph, with the host synchronising with the stream after five replays -- the pattern of bench.py's
+    warm-up / barrier / timed loop.  The non-deep form of lstm_rs_bwd_kernel returned wrong gate gradients from the
+    second replay after such a sync on (gradient norm ~1e4 instead of ~15, loss stuck at 4.66 while eager steps
+    reach 3.53); ops.DualPathRNN.backward keeps it off the default path.  The graph must track eager steps."""
+    import argparse
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from dtt_amd.dist import GradBucketReducer
+    dev = torch.device("cuda", 0)
+    losses = {}
+    for mode in ("0", "1"):
+        args = argparse.Namespace(batch=None, precision="bf16", graph=mode)
+        w = bench.build_workload("xattn60m", args, dev, 0, 1, GradBucketReducer)
+        assert w["mode"] == ("hip-graph" if mode == "1" else "eager")
+        for i in range(5):
+            l = w["step"](i)
+        torch.cuda.current_stream().synchronize()
+        for i in range(5, 24):
+            l = w["step"](i)
+        torch.cuda.synchronize()
+        losses[mode] = float(l.detach())
+        norm = float(w["opt"]._built["norm"])
+        assert norm < 200.0, f"gradient norm {norm} in mode {mode}"
+        del w
+        torch.cuda.empty_cache()
+    assert losses["0"] < 4.45 and abs(losses["1"] - losses["0"]) < 0.05, losses

@@ -59,7 +59,8 @@ class GraphedTrainStep:
     (collate.py:72-83), e.g. by running the GPU STFT; it is recorded with the rest.  ``inputs`` is any
     nest of CUDA tensors with the shapes every later batch will have."""
 
-    def __init__(self, model, criterion, optimizer, inputs, batch_fn, reducer=None, warmup=2, pack_plan=None):
+    def __init__(self, model, criterion, optimizer, inputs, batch_fn, reducer=None, warmup=2, pack_plan=None,
+                 handoff_kernels=False):
         if not torch.cuda.is_available():
             raise DttError("GraphedTrainStep needs an MI355X")
         self.model, self.criterion, self.opt, self.reducer = model, criterion, optimizer, reducer
@@ -77,6 +78,11 @@ class GraphedTrainStep:
         if pack_plan is None:
             pack_plan = os.environ.get("DTT_PACK_PLAN", "0") == "1"
         ops.weight_plan(pack_plan)
+        # The cross-CU hand-off LSTM kernels (H >= 512) stay out of the recorded step unless asked for: replayed, they
+        # returned wrong gradients after a host-side stream sync between replays (DESIGN finding 34); the streaming
+        # kernels take their place (slower: prefer eager steps for such models, as bench.py does).
+        prev_handoff = ops._HANDOFF
+        ops.handoff_kernels(handoff_kernels or os.environ.get("DTT_GRAPH_HANDOFF", "0") == "1")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager warm-up on the side stream (torch's recipe):
@@ -100,6 +106,7 @@ class GraphedTrainStep:
                 self.static_loss = loss.detach()
         finally:
             ops.reset_zero_arena()                         # later eager work must not carve from the graph's arena
+            ops.handoff_kernels(prev_handoff)              # only what is RECORDED avoids the hand-off kernels
             if reducer is not None:
                 reducer.pause_hooks(False)
         self.graph_grads = [p.grad for p in self.params]   # written in place by every replay: keep them alive

@@ -754,9 +754,23 @@ def _cluster_geometry(N, H, d):
     return U.value, G.value, S.value
 
 
+_HANDOFF = True
+
+
+def handoff_kernels(enabled=True):
+    """Allow / forbid the recurrent kernels whose CUs hand data to each other inside one launch (lstm_rs.hip,
+    lstm_cluster.hip).  GraphedTrainStep forbids them while it records (DESIGN finding 34): replayed inside a HIP
+    graph they returned wrong gradients once the host had synchronised with the stream between two replays, while
+    the same launches issued eagerly, and the streaming kernels inside the graph, stay exact.  Process-wide, like
+    the pack plan; the setting at FORWARD time decides for the backward of that forward too."""
+    global _HANDOFF
+    _HANDOFF = bool(enabled)
+
+
 def _lstm_mode():
     """DTT_LSTM = auto | rs | cluster | stream (A/B switch between the recurrent kernel families)."""
-    return os.environ.get("DTT_LSTM", "auto")
+    mode = os.environ.get("DTT_LSTM", "auto")
+    return "stream" if (mode == "auto" and not _HANDOFF) else mode
 
 
 def _rs_ok(N, H, d, heads, mode):
@@ -890,17 +904,6 @@ class DualPathRNN(torch.autograd.Function):
         # recurrent backward
         dG = _empty((R, 2, 4 * H), dt, dev)
         dbias = None
-        # The NON-deep form of lstm_rs_bwd_kernel (clusters with < 3 tiles: the frequency-axis pass) is not used by
-        # default (DESIGN finding 34): inside a replayed HIP graph, once the host had synchronised with the stream, it
-        # returned wrong gate gradients from the second replay on (the loss stops falling, the gradient norm jumps
-        # from ~15 to ~1e4; eager launches, the forward kernels and the deep form on the time axis are not affected,
-        # and the parity tests pass).  Until that is understood the frequency-axis backward of an rs forward runs on
-        # the LDS-cluster kernel, which reads the same saved layout.  DTT_LSTM_BWD = rs_time | cluster | rs | rs_freq.
-        bsel = os.environ.get("DTT_LSTM_BWD", "rs_time")
-        if rs and (bsel == "cluster" or (bsel == "rs_time" and along_f) or (bsel == "rs_freq" and not along_f)):
-            geom_c = _cluster_geometry(nslab * heads, H, d)
-            if geom_c is not None:
-                rs, geom = False, geom_c
         if rs:
             N = nslab * heads
             NT = (N + 31) // 32

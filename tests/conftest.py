@@ -61,3 +61,4 @@ def _pack_plan_off():
     mod = sys.modules.get("dtt_amd.ops")
     if mod is not None:
         mod.weight_plan(False)
+        mod.handoff_kernels(True)

@@ -128,12 +128,7 @@ def test_pack_plan_matches_plain_steps():
     assert close(g0, g1) and close(g0, g2) and close(g4, g3)
 
 
-def test_bench_step_keeps_learning_after_a_host_sync():
-    """The default bench workload (cfg4: x-attn 60M, B = 16, bf16, H = 512 register-stationary LSTM kernels) as a
-    replayed HIP graph, with the host synchronising with the stream after five replays -- the pattern of bench.py's
-    warm-up / barrier / timed loop.  The non-deep form of lstm_rs_bwd_kernel returned wrong gate gradients from the
-    second replay after such a sync on (gradient norm ~1e4 instead of ~15, loss stuck at 4.66 while eager steps
-    reach 3.53); ops.DualPathRNN.backward keeps it off the default path.  The graph must track eager steps."""
+def _bench_workload(mode):
     import argparse
     import os
     import sys
@@ -141,12 +136,21 @@ def test_bench_step_keeps_learning_after_a_host_sync():
     sys.path.insert(0, root)
     import bench
     from dtt_amd.dist import GradBucketReducer
-    dev = torch.device("cuda", 0)
+    args = argparse.Namespace(batch=None, precision="bf16", graph=mode)
+    w = bench.build_workload("xattn60m", args, torch.device("cuda", 0), 0, 1, GradBucketReducer)
+    assert w["mode"] == ("hip-graph" if mode == "1" else "eager")
+    return w
+
+
+def test_bench_step_keeps_learning_after_a_host_sync():
+    """The default bench workload (cfg4: x-attn 60M, B = 16, bf16, H = 512 LSTMs) as a replayed HIP graph, with the
+    host synchronising with the stream after five replays -- the pattern of bench.py's warm-up / barrier / timed
+    loop.  The non-deep form of lstm_rs_bwd_kernel returned wrong gate gradients from the second replay after such
+    a sync on (gradient norm ~1e4 instead of ~15, loss stuck at 4.66 while eager steps reach 3.53: DESIGN finding
+    34); GraphedTrainStep keeps the hand-off kernels out of what it records.  The graph must track eager steps."""
     losses = {}
     for mode in ("0", "1"):
-        args = argparse.Namespace(batch=None, precision="bf16", graph=mode)
-        w = bench.build_workload("xattn60m", args, dev, 0, 1, GradBucketReducer)
-        assert w["mode"] == ("hip-graph" if mode == "1" else "eager")
+        w = _bench_workload(mode)
         for i in range(5):
             l = w["step"](i)
         torch.cuda.current_stream().synchronize()
@@ -159,3 +163,41 @@ def test_bench_step_keeps_learning_after_a_host_sync():
         del w
         torch.cuda.empty_cache()
     assert losses["0"] < 4.45 and abs(losses["1"] - losses["0"]) < 0.05, losses
+
+
+def test_bench_graph_gradients_match_eager_after_a_host_sync():
+    """Same workload with the learning rate at zero (weights stay put): the gradients a replay leaves behind -- before
+    a host sync, and three replays after one -- against an eager forward + backward over the same batch and weights,
+    parameter by parameter.  A loss curve cannot see a gradient that is wrong but bounded; this can."""
+    w = _bench_workload("1")
+    gs = w["step"].__defaults__[0]
+    for grp in w["opt"].param_groups:
+        grp["lr"], grp["weight_decay"] = 0.0, 0.0
+    names = [k for k, p in w["model"].named_parameters() if p.requires_grad]
+
+    def replay_grads(n):
+        for _ in range(n):
+            w["step"](0)
+        torch.cuda.synchronize()
+        return [g.detach().clone() for g in gs.graph_grads]
+
+    before = replay_grads(3)
+    torch.cuda.current_stream().synchronize()
+    after = replay_grads(3)
+    gs.reducer.zero_grad()
+    for p in gs.params:
+        p.grad = None
+    from dtt_amd import ops
+    ops.handoff_kernels(False)                 # the kernels the graph recorded (bf16: another family differs by rounding)
+    loss = gs._fwd_bwd()
+    ops.handoff_kernels(True)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(gs.static_loss)) < 2e-3
+    worst = []
+    for k, p, gb, ga in zip(names, gs.params, before, after):
+        ref = p.grad.float()
+        scale = float(ref.norm()) + 1e-6
+        eb, ea = float((gb.float() - ref).norm()) / scale, float((ga.float() - ref).norm()) / scale
+        if max(eb, ea) > 3e-2 and scale > 1e-4:
+            worst.append((max(eb, ea), k, eb, ea, scale))
+    assert not worst, sorted(worst, reverse=True)[:8]

@@ -9,9 +9,8 @@ gradient all-reduce when N > 1) -> gradient clip -> AdamW step, on one batch of
 synthetic 2-speaker 16 kHz mixtures (+ 25 fps 88x88 lip ROI streams) that is
 already resident in HBM.  Weak scaling: the per-GPU batch is fixed.  The default
 workload is the north-star target, BASELINE.json configs[3]: DTTNet AV
-cross-attention 60M, B = 16 x 2 s, bf16.  The audio-only / FiLM steps are recorded
-once into a HIP graph and replayed (dtt_amd.GraphedTrainStep); the x-attn steps
-are issued eagerly (``--graph`` overrides either; DESIGN.md finding 34).
+cross-attention 60M, B = 16 x 2 s, bf16.  The step is recorded once into a HIP
+graph and replayed (dtt_amd.GraphedTrainStep); ``--graph 0`` issues it eagerly.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -138,10 +137,7 @@ def build_workload(name, args, dev, rank, world, reducer_cls):
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     decay = [p for n, p in named if "bias" not in n]
     no_decay = [p for n, p in named if "bias" in n]
-    # auto: one HIP graph per step, except for the x-attn models: their H >= 512 LSTMs run on cross-CU hand-off
-    # kernels, which GraphedTrainStep keeps out of a recorded step (DESIGN finding 34: wrong gradients when replayed
-    # after a host sync) -- the eager step with them is GPU-bound and as fast as the replay was
-    use_graph = args.graph == "1" or (args.graph == "auto" and cfg["model"] != "xattn")
+    use_graph = args.graph != "0"
     # clip_grad_norm_(2.0) + AdamW (train.yaml:20-23,59) in two launches
     opt = dtt_amd.ClipAdamW([{"params": decay, "weight_decay": 1e-5}, {"params": no_decay, "weight_decay": 0.0}],
                             lr=1e-4, max_norm=2.0, capturable=use_graph and world == 1)
@@ -236,8 +232,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", default="auto", choices=["auto", "0", "1"],
-                    help="record the step into a HIP graph and replay it (auto: graph for the audio-only / FiLM workloads, "
-                         "eager launches for the x-attn ones; falls back to eager if capture fails)")
+                    help="record the step into a HIP graph and replay it (auto: fall back to eager if capture fails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary audio15m (configs[1]) measurement")

@@ -627,6 +627,14 @@ extern "C" int dtt_lstm_cluster_geometry(int N, int H, int dtype, int* U, int* G
     return 0;
 }
 
+// The hand-off counters are zeroed by a KERNEL, not by hipMemsetAsync: recorded into a HIP graph, the memset nodes
+// were the one thing these entry points had that the streaming kernels had not, and replayed after a host-side
+// stream sync the step then returned wrong gradients (DESIGN.md finding 34).
+static __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 extern "C" int dtt_lstm_cluster_sync_words(int S) { return (2 * S + 1) * (int)SYNC_STRIDE; }
 
 extern "C" int dtt_lstm_cluster_fwd(const void* xg, const void* whh, void* y, void* gates_blk, float* cst_blk,
@@ -641,7 +649,7 @@ extern "C" int dtt_lstm_cluster_fwd(const void* xg, const void* whh, void* y, vo
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool wlds = dtype == 1 && cluster_fwd_lds(H, U, es, true) <= LDS_CAP;
     const size_t sm = cluster_fwd_lds(H, U, es, wlds);
-    DTT_CHECK(hipMemsetAsync(sync, 0, (size_t)dtt_lstm_cluster_sync_words(S) * 4, st) == hipSuccess, "dtt_lstm_cluster_fwd: memset failed");
+    { const int nw = dtt_lstm_cluster_sync_words(S); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
     const dim3 grid(2 * S * G), block(512);
 #define LAUNCH_CF(TT, UTV, WL) do { auto k = lstm_cluster_fwd_kernel<TT, UTV, WL>; \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
@@ -675,7 +683,7 @@ extern "C" int dtt_lstm_cluster_bwd(const void* dy, const void* gates_blk, const
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool wlds = dtype == 1 && cluster_bwd_lds(H, U, es, true) <= LDS_CAP;
     const size_t sm = cluster_bwd_lds(H, U, es, wlds);
-    DTT_CHECK(hipMemsetAsync(sync, 0, (size_t)dtt_lstm_cluster_sync_words(S) * 4, st) == hipSuccess, "dtt_lstm_cluster_bwd: memset failed");
+    { const int nw = dtt_lstm_cluster_sync_words(S); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
     const dim3 grid(2 * S * G), block(512);
 #define LAUNCH_CB(TT, UTV, WL) do { auto k = lstm_cluster_bwd_kernel<TT, UTV, WL>; \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \

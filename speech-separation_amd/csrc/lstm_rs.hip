@@ -905,6 +905,14 @@ extern "C" int dtt_lstm_rs_supported(int N, int H, int dtype) {
     return rs_geometry(N, H, dtype, false, G, S, NT, TMAX) && rs_geometry(N, H, dtype, true, G, S, NT, TMAX) ? 0 : 1;
 }
 
+// The hand-off counters are zeroed by a KERNEL, not by hipMemsetAsync: recorded into a HIP graph, the memset nodes
+// were the one thing these entry points had that the streaming kernels had not, and replayed after a host-side
+// stream sync the step then returned wrong gradients (DESIGN.md finding 34).
+static __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 extern "C" int dtt_lstm_rs_sync_words(int N, int H) {
     int G, S, NT, TMAX, words = 0;
     for (int bwd = 0; bwd < 2; ++bwd) {                     // one size serves both calls
@@ -925,7 +933,7 @@ extern "C" int dtt_lstm_rs_fwd(const void* xg, const void* whh, void* y, void* g
     DTT_CHECK((int64_t)N * L * 2 * 4 * H * 2 < (1LL << 32) - 64, "dtt_lstm_rs_fwd: xg exceeds 32-bit byte offsets");
     LstmRF p{xg, whh, y, gates_blk, cst_blk, sync, N, L, hshift, S, NT, TMAX};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    DTT_CHECK(hipMemsetAsync(sync, 0, (size_t)dtt_lstm_rs_sync_words(N, H) * 4, st) == hipSuccess, "dtt_lstm_rs_fwd: memset failed");
+    { const int nw = dtt_lstm_rs_sync_words(N, H); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
     const dim3 grid(2 * S * G), block(256);
     const int U = H / G;
     const size_t sm = ((size_t)2 * 32 * (H + 8) + (size_t)32 * (U + 8)) * 2;
@@ -958,7 +966,7 @@ extern "C" int dtt_lstm_rs_bwd(const void* dy, const void* gates_blk, const floa
     DTT_CHECK((int64_t)N * L * 2 * 4 * H * 2 < (1LL << 32) - 64, "dtt_lstm_rs_bwd: dG exceeds 32-bit byte offsets");
     LstmRB p{dy, gates_blk, cst_blk, whhT, dG, dcbuf, dbias, sync, N, L, hshift, S, NT, TMAX};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    DTT_CHECK(hipMemsetAsync(sync, 0, (size_t)dtt_lstm_rs_sync_words(N, H) * 4, st) == hipSuccess, "dtt_lstm_rs_bwd: memset failed");
+    { const int nw = dtt_lstm_rs_sync_words(N, H); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
     const dim3 grid(2 * S * G), block(256);
     const int U = H / G, MTB = U / 16;
     const size_t sm = (size_t)4 * MTB * 2 * 64 * 16 + (size_t)32 * (4 * U + 8) * 2 + (size_t)4 * 16 * (H + 8) * 2;

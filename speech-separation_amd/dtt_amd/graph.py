@@ -60,7 +60,7 @@ class GraphedTrainStep:
     nest of CUDA tensors with the shapes every later batch will have."""
 
     def __init__(self, model, criterion, optimizer, inputs, batch_fn, reducer=None, warmup=2, pack_plan=None,
-                 handoff_kernels=False):
+                 handoff_kernels=True):
         if not torch.cuda.is_available():
             raise DttError("GraphedTrainStep needs an MI355X")
         self.model, self.criterion, self.opt, self.reducer = model, criterion, optimizer, reducer
@@ -78,11 +78,12 @@ class GraphedTrainStep:
         if pack_plan is None:
             pack_plan = os.environ.get("DTT_PACK_PLAN", "0") == "1"
         ops.weight_plan(pack_plan)
-        # The cross-CU hand-off LSTM kernels (H >= 512) stay out of the recorded step unless asked for: replayed, they
-        # returned wrong gradients after a host-side stream sync between replays (DESIGN finding 34); the streaming
-        # kernels take their place (slower: prefer eager steps for such models, as bench.py does).
+        # handoff_kernels=False (or DTT_GRAPH_HANDOFF=0) keeps the cross-CU hand-off LSTM kernels (H >= 512) out of
+        # the recorded step (streaming kernels instead).  They are safe to record since their counters are zeroed by
+        # a kernel: as hipMemsetAsync NODES of the graph those resets made replays after a host-side stream sync
+        # return wrong gradients (DESIGN finding 34).
         prev_handoff = ops._HANDOFF
-        ops.handoff_kernels(handoff_kernels or os.environ.get("DTT_GRAPH_HANDOFF", "0") == "1")
+        ops.handoff_kernels(handoff_kernels and os.environ.get("DTT_GRAPH_HANDOFF", "1") != "0")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager warm-up on the side stream (torch's recipe):

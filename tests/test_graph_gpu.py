@@ -147,7 +147,7 @@ def test_bench_step_keeps_learning_after_a_host_sync():
     host synchronising with the stream after five replays -- the pattern of bench.py's warm-up / barrier / timed
     loop.  The non-deep form of lstm_rs_bwd_kernel returned wrong gate gradients from the second replay after such
     a sync on (gradient norm ~1e4 instead of ~15, loss stuck at 4.66 while eager steps reach 3.53: DESIGN finding
-    34); GraphedTrainStep keeps the hand-off kernels out of what it records.  The graph must track eager steps."""
+    34), because their counters were reset by hipMemsetAsync nodes; a kernel resets them now.  The graph must track eager steps."""
     losses = {}
     for mode in ("0", "1"):
         w = _bench_workload(mode)
@@ -187,10 +187,7 @@ def test_bench_graph_gradients_match_eager_after_a_host_sync():
     gs.reducer.zero_grad()
     for p in gs.params:
         p.grad = None
-    from dtt_amd import ops
-    ops.handoff_kernels(False)                 # the kernels the graph recorded (bf16: another family differs by rounding)
-    loss = gs._fwd_bwd()
-    ops.handoff_kernels(True)
+    loss = gs._fwd_bwd()                        # same kernel families as recorded (ops.handoff_kernels is restored)
     torch.cuda.synchronize()
     assert abs(float(loss) - float(gs.static_loss)) < 2e-3
     worst = []

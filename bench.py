@@ -197,8 +197,11 @@ def time_workload(w, steps, warmup, world, dev, backend):
         torch.cuda.synchronize()
 
     loss = None
+    w["first_loss"] = None
     for i in range(warmup):
         loss = w["step"](i)
+        if i == 0:
+            w["first_loss"] = float(loss.detach())      # beside final_loss: the timed steps must train (DESIGN finding 34)
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -270,6 +273,7 @@ def main():
     cfg, B, launch_mode = w["cfg"], w["B"], w["mode"]
     elapsed, enqueue, loss_val = time_workload(w, args.steps, args.warmup, world, dev, backend)
     host_issue_ms = w["host_issue_ms"]
+    w_first = w["first_loss"]
 
     # SURVEY 8(d) wants the optimizer's share stated beside the step: events on the launch stream around a few
     # extra clip+AdamW calls on the last step's gradients (outside the timed region)
@@ -312,7 +316,7 @@ def main():
             "config": {"workload": f"{args.workload}: {NAMES[cfg['model']]} training step (STFT+fwd+PIT-L1+bwd"
                                    f"+clip+AdamW), B={B}/GPU x {cfg['seconds']:.0f} s, n_fft 1024 hop 256",
                        "global_batch": B * world, "parallelism": f"dp{world}", "launch": launch_mode,
-                       "final_loss": round(loss_val, 4),
+                       "first_loss": None if w_first is None else round(w_first, 4), "final_loss": round(loss_val, 4),
                        "host_issue_ms_per_step": round(host_issue_ms, 2),
                        "host_enqueue_ms_per_step_back_to_back": round(enqueue / args.steps * 1e3, 2),
                        "clip_adamw_ms_per_step": round(opt_ms, 3),

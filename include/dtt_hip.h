@@ -203,6 +203,24 @@ int dtt_lstm_rs_fwd(const void* xg, const void* whh, void* y, void* gates_blk, f
 int dtt_lstm_rs_bwd(const void* dy, const void* gates_blk, const float* cst_blk, const void* whhT, void* dG,
                     float* dcbuf, float* dbias, unsigned* sync, int N, int L, int heads, int H, int dtype,
                     void* stream);
+/* As dtt_lstm_rs_supported, with the step count: 1 also when N * L exceeds the 32-bit byte offsets of xg / dG or the
+ * 31-bit offsets of the saved activations (the launch would be refused): the caller falls back to
+ * dtt_lstm_cluster_* / dtt_lstm_*. */
+int dtt_lstm_rs_covers(int N, int L, int H, int dtype);
+
+/* Hand-off health (no counterpart in the reference: nn.LSTM, latent.py:87-92, cannot fail this way).  The
+ * dtt_lstm_rs_* and dtt_lstm_cluster_* launches need all their workgroups co-resident (one per CU); a workgroup
+ * that waits ~0.5 s for a peer gives up, raises the launch's status word (sync[0] / the tail word) AND a sticky
+ * per-GPU word, and runs to completion on stale tiles: the results of that launch are garbage.
+ *   dtt_lstm_{rs,cluster}_status_fold: one tiny launch on `stream`: *flag |= 1 (rs) / 2 (cluster) when a launch of
+ *     that family has timed out on the current GPU since the last clear; clear != 0 re-arms the sticky word.
+ *     flag: one uint32 in device memory (may be NULL with clear != 0).
+ *   dtt_lstm_{rs,cluster}_diag_drop_workgroups(n): diagnostic -- the next launch of that family starts n workgroups
+ *     short (what a CU-masked partition does to it), so tests can see the product notice. */
+int dtt_lstm_rs_status_fold(unsigned* flag, int clear, void* stream);
+int dtt_lstm_cluster_status_fold(unsigned* flag, int clear, void* stream);
+void dtt_lstm_rs_diag_drop_workgroups(int n);
+void dtt_lstm_cluster_diag_drop_workgroups(int n);
 
 /* Every derived weight tensor of a step in one launch: the casts / permuted / stacked / transposed copies of
  * parameters that the reference's modules get from autocast and from PyTorch's own weight layouts

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 __all__ = [
     "stft_complex", "stft_mag_phase", "istft_rect", "conv_norm_gelu", "tfc_tdf",
-    "encoder", "lstm_bidir", "tc_fc_rnn", "idp", "latent", "decoder", "mask_recon",
+    "encoder", "lstm_dir", "lstm_bidir", "tc_fc_rnn", "idp", "latent", "decoder", "mask_recon",
     "dttnet_forward", "film", "cross_attention_positional", "temporal_aligner",
     "resnet18_video_encoder", "lipreading_video_features", "dttnet_vision_forward", "dttnet_film_forward",
     "dttnet_l1", "pit_loss", "fixed_order_loss", "si_snr", "si_snr_i",
@@ -150,6 +150,24 @@ def encoder(sd, p, spec, phase, taps=None):
     return x, skips
 
 
+def lstm_dir(xin, w_hh, rev):
+    """One direction of the recurrence on pre-computed input projections: xin [N, L, 4H] = x W_ih^T + b_ih + b_hh,
+    gate order i,f,g,o, zero initial state (modules/latent.py:87-92) -> h [N, L, H]."""
+    N, L, _ = xin.shape
+    H = w_hh.shape[1]
+    h = xin.new_zeros(N, H)
+    c = xin.new_zeros(N, H)
+    ys = [None] * L
+    order = range(L - 1, -1, -1) if rev else range(L)
+    for t in order:
+        g = xin[:, t] + F.linear(h, w_hh)
+        i_, f_, g_, o_ = g.chunk(4, dim=1)
+        c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
+        h = torch.sigmoid(o_) * torch.tanh(c)
+        ys[t] = h
+    return torch.stack(ys, dim=1)
+
+
 def lstm_bidir(x, sd, p):
     """Single-layer bidirectional ``nn.LSTM(batch_first=True)`` with zero
     initial state, gate order i,f,g,o (modules/latent.py:87-92), as an explicit
@@ -159,20 +177,7 @@ def lstm_bidir(x, sd, p):
         w_ih = sd[f"{p}weight_ih_l0{suffix}"]
         w_hh = sd[f"{p}weight_hh_l0{suffix}"]
         bias = sd[f"{p}bias_ih_l0{suffix}"] + sd[f"{p}bias_hh_l0{suffix}"]
-        H = w_hh.shape[1]
-        N, L, _ = x.shape
-        xin = F.linear(x, w_ih, bias)                         # [N,L,4H]
-        h = x.new_zeros(N, H)
-        c = x.new_zeros(N, H)
-        ys = [None] * L
-        order = range(L - 1, -1, -1) if rev else range(L)
-        for t in order:
-            g = xin[:, t] + F.linear(h, w_hh)
-            i_, f_, g_, o_ = g.chunk(4, dim=1)
-            c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
-            h = torch.sigmoid(o_) * torch.tanh(c)
-            ys[t] = h
-        outs.append(torch.stack(ys, dim=1))
+        outs.append(lstm_dir(F.linear(x, w_ih, bias), w_hh, rev))      # xin [N,L,4H]
     return torch.cat(outs, dim=-1)
 
 

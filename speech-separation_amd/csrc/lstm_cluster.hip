@@ -80,6 +80,10 @@ template <> struct AFrag<float> {
     }
 };
 
+// Sticky, one per GPU: raised (never cleared by a kernel) by any launch of this file whose poll timed out; read
+// through dtt_lstm_cluster_status_fold (the per-launch status word is reset by the next call on its buffer).
+static __device__ unsigned g_cluster_timeouts;
+
 // One lane polls, the workgroup barrier releases the others (sc1 table, first row).
 // `dead` (kept by the polling lane): a wait of this workgroup has timed out once -- a workgroup of the launch is not
 // resident or the launch is broken -- so every later wait is skipped and the kernel drains (results are garbage;
@@ -91,6 +95,7 @@ __device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, uns
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT) {
                 __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&g_cluster_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dead = true;
                 break;
             }
@@ -635,6 +640,29 @@ static __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __rest
     if (i < n) p[i] = 0u;
 }
 
+static __global__ void cluster_status_fold_kernel(unsigned* __restrict__ flag, unsigned bit, int clear) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (g_cluster_timeouts && flag) atomicOr(flag, bit);
+        if (clear) g_cluster_timeouts = 0u;
+    }
+}
+
+// flag |= 2 when a launch of this file has timed out on this GPU since the last clear (clear != 0 re-arms it)
+extern "C" int dtt_lstm_cluster_status_fold(unsigned* flag, int clear, void* stream) {
+    hipLaunchKernelGGL(cluster_status_fold_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), flag, 2u, clear);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+// Diagnostic, as dtt_lstm_rs_diag_drop_workgroups: the next cluster launch starts n workgroups short.
+static int g_cluster_diag_drop = 0;
+extern "C" void dtt_lstm_cluster_diag_drop_workgroups(int n) { g_cluster_diag_drop = n > 0 ? n : 0; }
+static unsigned cluster_grid(int full) {
+    const int drop = std::min(g_cluster_diag_drop, full - 1);
+    g_cluster_diag_drop = 0;
+    return (unsigned)(full - drop);
+}
+
 extern "C" int dtt_lstm_cluster_sync_words(int S) { return (2 * S + 1) * (int)SYNC_STRIDE; }
 
 extern "C" int dtt_lstm_cluster_fwd(const void* xg, const void* whh, void* y, void* gates_blk, float* cst_blk,
@@ -650,7 +678,7 @@ extern "C" int dtt_lstm_cluster_fwd(const void* xg, const void* whh, void* y, vo
     const bool wlds = dtype == 1 && cluster_fwd_lds(H, U, es, true) <= LDS_CAP;
     const size_t sm = cluster_fwd_lds(H, U, es, wlds);
     { const int nw = dtt_lstm_cluster_sync_words(S); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
-    const dim3 grid(2 * S * G), block(512);
+    const dim3 grid(cluster_grid(2 * S * G)), block(512);
 #define LAUNCH_CF(TT, UTV, WL) do { auto k = lstm_cluster_fwd_kernel<TT, UTV, WL>; \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
@@ -684,7 +712,7 @@ extern "C" int dtt_lstm_cluster_bwd(const void* dy, const void* gates_blk, const
     const bool wlds = dtype == 1 && cluster_bwd_lds(H, U, es, true) <= LDS_CAP;
     const size_t sm = cluster_bwd_lds(H, U, es, wlds);
     { const int nw = dtt_lstm_cluster_sync_words(S); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
-    const dim3 grid(2 * S * G), block(512);
+    const dim3 grid(cluster_grid(2 * S * G)), block(512);
 #define LAUNCH_CB(TT, UTV, WL) do { auto k = lstm_cluster_bwd_kernel<TT, UTV, WL>; \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)

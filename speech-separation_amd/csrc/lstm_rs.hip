@@ -86,6 +86,11 @@ __device__ __forceinline__ void rs_role(int b, int G, int S, int& dir, int& sg, 
     sg = q - dir * S;
 }
 
+// Sticky, one per GPU: raised (never cleared by a kernel) by any launch of this file whose poll timed out.  The
+// per-launch status word at sync[0] is reset by the next call on that buffer; this one survives until the host
+// reads it (dtt_lstm_rs_status_fold), so the product can check it where it synchronises anyway.
+static __device__ unsigned g_rs_timeouts;
+
 // every wave polls for itself (lane 0), the rest of the wave reconverges behind it
 __device__ __forceinline__ void rs_wait(unsigned* cnt, unsigned target, unsigned* status, bool& dead) {
     if ((threadIdx.x & 63) == 0 && !dead) {
@@ -94,6 +99,7 @@ __device__ __forceinline__ void rs_wait(unsigned* cnt, unsigned target, unsigned
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT) {
                 __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&g_rs_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dead = true;
                 break;
             }
@@ -905,12 +911,46 @@ extern "C" int dtt_lstm_rs_supported(int N, int H, int dtype) {
     return rs_geometry(N, H, dtype, false, G, S, NT, TMAX) && rs_geometry(N, H, dtype, true, G, S, NT, TMAX) ? 0 : 1;
 }
 
+extern "C" int dtt_lstm_rs_covers(int N, int L, int H, int dtype) {
+    if (dtt_lstm_rs_supported(N, H, dtype) != 0 || L <= 0) return 1;
+    const int64_t NT = (N + 31) / 32;
+    if ((int64_t)N * L * 2 * 4 * H * 2 >= (1LL << 32) - 64) return 1;          // xg / dG byte offsets (32-bit)
+    if ((int64_t)2 * NT * L * H * 32 * 4 >= (1LL << 31)) return 1;              // saved cell states (31-bit)
+    return 0;
+}
+
 // The hand-off counters are zeroed by a KERNEL, not by hipMemsetAsync: recorded into a HIP graph, the memset nodes
 // were the one thing these entry points had that the streaming kernels had not, and replayed after a host-side
 // stream sync the step then returned wrong gradients (DESIGN.md finding 34).
 static __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0u;
+}
+
+// flag |= bit when a launch of this file has timed out on this GPU since the last clear (clear != 0 re-arms it).
+static __global__ void rs_status_fold_kernel(unsigned* __restrict__ flag, unsigned bit, int clear) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (g_rs_timeouts && flag) atomicOr(flag, bit);
+        if (clear) g_rs_timeouts = 0u;
+    }
+}
+
+extern "C" int dtt_lstm_rs_status_fold(unsigned* flag, int clear, void* stream) {
+    hipLaunchKernelGGL(rs_status_fold_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), flag, 1u, clear);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+// Diagnostic: the NEXT dtt_lstm_rs_fwd / _bwd launch of this process starts n workgroups short, i.e. one cluster
+// lacks members, exactly what a CU-masked partition or a foreign kernel holding a CU does to these launches.  The
+// remaining workgroups time out (bounded spins), raise the status words and run to completion on stale tiles; no
+// access leaves the buffers.  tests/test_handoff_status_gpu.py uses it to prove that the product notices.
+static int g_rs_diag_drop = 0;
+extern "C" void dtt_lstm_rs_diag_drop_workgroups(int n) { g_rs_diag_drop = n > 0 ? n : 0; }
+static unsigned rs_grid(int full) {
+    const int drop = std::min(g_rs_diag_drop, full - 1);
+    g_rs_diag_drop = 0;
+    return (unsigned)(full - drop);
 }
 
 extern "C" int dtt_lstm_rs_sync_words(int N, int H) {
@@ -934,7 +974,7 @@ extern "C" int dtt_lstm_rs_fwd(const void* xg, const void* whh, void* y, void* g
     LstmRF p{xg, whh, y, gates_blk, cst_blk, sync, N, L, hshift, S, NT, TMAX};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     { const int nw = dtt_lstm_rs_sync_words(N, H); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
-    const dim3 grid(2 * S * G), block(256);
+    const dim3 grid(rs_grid(2 * S * G)), block(256);
     const int U = H / G;
     const size_t sm = ((size_t)2 * 32 * (H + 8) + (size_t)32 * (U + 8)) * 2;
 #define LAUNCH_RF(MTV, KSV, DP) do { auto k = lstm_rs_fwd_kernel<MTV, KSV, DP>; \
@@ -967,7 +1007,7 @@ extern "C" int dtt_lstm_rs_bwd(const void* dy, const void* gates_blk, const floa
     LstmRB p{dy, gates_blk, cst_blk, whhT, dG, dcbuf, dbias, sync, N, L, hshift, S, NT, TMAX};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     { const int nw = dtt_lstm_rs_sync_words(N, H); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
-    const dim3 grid(2 * S * G), block(256);
+    const dim3 grid(rs_grid(2 * S * G)), block(256);
     const int U = H / G, MTB = U / 16;
     const size_t sm = (size_t)4 * MTB * 2 * 64 * 16 + (size_t)32 * (4 * U + 8) * 2 + (size_t)4 * 16 * (H + 8) * 2;
 #define LAUNCH_RB(MTV, KSV, DP) do { auto k = lstm_rs_bwd_kernel<MTV, KSV, DP>; \

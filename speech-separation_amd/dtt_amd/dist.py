@@ -150,6 +150,9 @@ class GradBucketReducer:
 
     def finish(self):
         """Wait for the outstanding all-reduces and turn sums into means."""
+        if torch.cuda.is_available() and self.params and self.params[0].is_cuda:
+            from . import ops
+            ops.handoff_poll(self.params[0].device)       # collectives ran beside backward: did a hand-off launch starve?
         if self.world == 1:
             return
         for bi in range(self._next, len(self.buckets)):   # buckets holding parameters that got no gradient,

@@ -133,6 +133,8 @@ class GraphedTrainStep:
         return loss
 
     def __call__(self, inputs=None):
+        """One training step.  Returns ``static_loss``: the SAME 0-dim device tensor every call, overwritten by the
+        next replay -- ``float()`` / ``.clone()`` it to keep a value."""
         if inputs is not None:
             _copy_into(self.static_in, inputs)
         if self.world == 1:
@@ -144,4 +146,12 @@ class GraphedTrainStep:
             self.reducer.reduce_grads(self.params, self.graph_grads)
             self.opt.step()
         self._replays += 1
+        # the recorded step may hold hand-off LSTM launches: queue a (non-blocking) status read behind the replay;
+        # a time-out raises DttError at the next call / loss / optimizer step, check() raises at once
+        ops.handoff_poll(used=True)
         return self.static_loss
+
+    def check(self):
+        """Blocking: synchronise with the stream and raise DttError if a hand-off launch of any replay so far
+        timed out (its step trained on garbage).  For loops that never read the loss on the host."""
+        ops.handoff_check()

@@ -48,6 +48,10 @@ def load_reference_checkpoint(model, checkpoint, map_location=None):
 
 def save_reference_checkpoint(path, model, epoch=0, optimizer=None, lr_scheduler=None, monitor_best=0.0, config=None):
     """base_trainer.py:596-625: the dict the reference's trainer writes (and ``_resume_checkpoint`` reads)."""
+    dev = next((p.device for p in model.parameters() if p.is_cuda), None)
+    if dev is not None:
+        from . import ops
+        ops.handoff_check(dev)      # never write weights that a timed-out hand-off launch may have poisoned
     state = {
         "arch": type(model).__name__,
         "epoch": epoch,

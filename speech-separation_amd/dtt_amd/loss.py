@@ -25,6 +25,7 @@ def _pit_l1(sources, preds, batch, fixed):
     if not pspec.is_cuda:
         raise DttError("dtt_amd losses run on an MI355X only (no CPU path)")
     src = ([s["spectrogram"] for s in sources] + [s["phase"] for s in sources] + [s["audio"] for s in sources])
+    ops.handoff_poll(pspec.device)          # hand-off LSTM kernels of this forward / the previous step: non-blocking
     item, permuts = ops.PitL1Loss.apply(pspec, pphase, paudio, fixed, *src)
     return item, permuts
 

@@ -59,7 +59,9 @@ def PIT_wrapper_training(improvement, audio, preds, sources, batch_permuts, **ba
     B = audio.shape[0]
     idx = batch_permuts.t().unsqueeze(1)                             # [P,1,B]
     score = m.gather(1, idx).squeeze(1).sum(0)                       # [B]
-    return (score / len(sources)).detach().cpu().mean()
+    out = (score / len(sources)).detach().cpu().mean()
+    ops.handoff_check(audio.device)                                  # the .cpu() above synchronised: read the status too
+    return out
 
 
 def PIT_wrapper_inference(improvement, audio, preds, sources, **batch):
@@ -74,7 +76,9 @@ def PIT_wrapper_inference(improvement, audio, preds, sources, **batch):
         rows.append(tot)
     scores = torch.stack(rows)
     best = scores.argmax(dim=0)
-    return (scores.gather(0, best.unsqueeze(0)).squeeze(0) / n).mean().cpu()
+    out = (scores.gather(0, best.unsqueeze(0)).squeeze(0) / n).mean().cpu()
+    ops.handoff_check(audio.device)
+    return out
 
 
 class SiSnrPITTraining(BaseMetric):

@@ -339,6 +339,8 @@ class DTTNetVisionModel(_SeparatorBase):
         x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
         if video_features is None:                      # (tests may feed encoder outputs directly)
             video_features = self.encode_video(video)
+            if _Tap.store is not None:
+                _Tap.store["video_encoder"] = video_features.detach().float()
         x = self.fusion(x, video_features)
         _Tap.put("fusion", x)
         x = self.latent(x)
@@ -380,6 +382,8 @@ class DTTNetPlusModel(_SeparatorBase):
                 raise DttError("video_features must be [B, T_v, 2048]")
             with torch.autocast("cuda", enabled=False):
                 video_encoded = self.video_encoder.post_processor(video_features.float())
+            if _Tap.store is not None:
+                _Tap.store["video_encoder"] = video_encoded.detach().float()
         x = self.latent(x, video_encoded)
         x = self.decoder(x, skips)
         return self.postprocess(x, spectrogram, phase, audio_length)

@@ -759,12 +759,115 @@ _HANDOFF = True
 
 def handoff_kernels(enabled=True):
     """Allow / forbid the recurrent kernels whose CUs hand data to each other inside one launch (lstm_rs.hip,
-    lstm_cluster.hip).  GraphedTrainStep forbids them while it records (DESIGN finding 34): replayed inside a HIP
-    graph they returned wrong gradients once the host had synchronised with the stream between two replays, while
-    the same launches issued eagerly, and the streaming kernels inside the graph, stay exact.  Process-wide, like
-    the pack plan; the setting at FORWARD time decides for the backward of that forward too."""
+    lstm_cluster.hip); with False `auto` selects the streaming kernels (lstm.hip), which need no co-residency.
+    They are recorded into HIP graphs by default since their counters are reset by a kernel (DESIGN finding 34:
+    as memset NODES those resets made replays after a host sync return wrong gradients);
+    GraphedTrainStep(handoff_kernels=False) / DTT_GRAPH_HANDOFF=0 keeps them out of a recorded step.
+    Process-wide, like the pack plan; the setting at FORWARD time decides for the backward of that forward too."""
     global _HANDOFF
     _HANDOFF = bool(enabled)
+
+
+# --------------------------------------------------------------------------- #
+# Hand-off health: the product reads the status words
+# --------------------------------------------------------------------------- #
+class _HandoffWatch:
+    """Per GPU.  A hand-off launch (lstm_rs.hip / lstm_cluster.hip) whose workgroups are not all co-resident -- a
+    CU-masked partition, a foreign kernel (RCCL beside backward) holding a CU, two processes on one card -- times
+    out after ~0.5 s, raises a sticky per-GPU status word and finishes on stale tiles: that step's activations and
+    gradients are garbage.  `poll` (non-blocking: loss wrappers, optimizer steps, graph replays, the reducer's
+    finish) folds the sticky words into a device flag and copies it to pinned host memory behind the work
+    already queued; the NEXT poll that finds the copy complete raises.  `check` (blocking: metrics, checkpoint
+    save, bench end, anything that synchronises anyway) does both at once."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = None
+
+    def fold(self, clear=0):
+        st = stream_ptr()
+        check(lib().dtt_lstm_rs_status_fold(ptr(self.flag), clear, st), "dtt_lstm_rs_status_fold")
+        check(lib().dtt_lstm_cluster_status_fold(ptr(self.flag), clear, st), "dtt_lstm_cluster_status_fold")
+
+    def fail(self, bits):
+        with torch.cuda.device(self.dev):
+            self.fold(clear=1)                       # re-arm: the caller may switch kernels and go on
+            self.flag.zero_()
+        self.host.zero_()
+        self.event = None
+        fam = " and ".join(n for b, n in ((1, "register-stationary (lstm_rs)"), (2, "LDS-cluster (lstm_cluster)")) if bits & b)
+        raise DttError(
+            f"a {fam} BiLSTM launch on {self.dev} timed out waiting for a peer workgroup: its hidden states / gate "
+            "gradients and everything computed from them since the last successful check are INVALID (discard the "
+            "step).  These kernels need all of their workgroups co-resident, one per CU: a CU-masked partition, "
+            "another process on the card or a foreign kernel holding CUs breaks that.  Use ops.handoff_kernels(False) "
+            "or DTT_LSTM=stream for the streaming kernels, which need no co-residency.")
+
+
+_WATCH = {}
+
+
+def _watch(dev=None):
+    if dev is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    w = _WATCH.get(key)
+    if w is None:
+        w = _WATCH[key] = _HandoffWatch(torch.device("cuda", key))
+    return w
+
+
+_HANDOFF_USED = set()        # device indices with hand-off launches issued since their last fold
+
+
+def _dev_index(dev):
+    return dev.index if dev is not None and dev.index is not None else torch.cuda.current_device()
+
+
+def _note_handoff(dev):
+    """Called at every hand-off launch site (also while a graph is being recorded: touches no tensor)."""
+    _HANDOFF_USED.add(_dev_index(dev))
+
+
+def handoff_poll(dev=None, used=None):
+    """Non-blocking health check of the hand-off LSTM kernels (see _HandoffWatch).  Raises DttError when a copy
+    queued by an EARLIER poll has arrived with a time-out in it; queues a new fold + copy when hand-off launches
+    were issued since (`used=True`: a graph replay holding such launches).  No-op while a stream is capturing."""
+    key = _dev_index(dev)
+    if used:
+        _HANDOFF_USED.add(key)
+    if torch.cuda.is_current_stream_capturing() or (key not in _WATCH and key not in _HANDOFF_USED):
+        return
+    w = _watch(torch.device("cuda", key))
+    if w.event is not None and w.event.query():
+        w.event = None
+        bits = int(w.host[0])
+        if bits:
+            w.fail(bits)
+    if w.event is None and key in _HANDOFF_USED:
+        _HANDOFF_USED.discard(key)
+        with torch.cuda.device(w.dev):
+            w.fold()
+            w.host.copy_(w.flag, non_blocking=True)
+            w.event = torch.cuda.Event()
+            w.event.record()
+
+
+def handoff_check(dev=None):
+    """Blocking form: everything queued on the current stream so far is covered.  Call it where the host
+    synchronises anyway (metrics' .cpu(), checkpoint save, end of a benchmark)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    w = _watch(dev)
+    _HANDOFF_USED.discard(_dev_index(w.dev))
+    with torch.cuda.device(w.dev):
+        w.fold()
+        bits = int(w.flag.item())
+    w.event = None
+    if bits:
+        w.fail(bits)
 
 
 def _lstm_mode():
@@ -773,13 +876,14 @@ def _lstm_mode():
     return "stream" if (mode == "auto" and not _HANDOFF) else mode
 
 
-def _rs_ok(N, H, d, heads, mode):
-    """Register-stationary kernels (lstm_rs.hip): bf16, H = 512 (auto) or H in {256, 512} (DTT_LSTM=rs)."""
+def _rs_ok(N, L, H, d, heads, mode):
+    """Register-stationary kernels (lstm_rs.hip): bf16, H = 512 (auto) or H in {256, 512} (DTT_LSTM=rs), and N * L
+    within the kernels' 32-bit offsets (beyond: the cluster / streaming kernels)."""
     if mode not in ("auto", "rs") or heads & (heads - 1) or heads > 32:
         return False
     if mode == "auto" and H != 512:
         return False
-    return lib().dtt_lstm_rs_supported(N, H, d) == 0
+    return lib().dtt_lstm_rs_covers(N, L, H, d) == 0
 
 
 class DualPathRNN(torch.autograd.Function):
@@ -817,7 +921,7 @@ class DualPathRNN(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         N = nslab * heads
         mode = _lstm_mode()
-        rs = _rs_ok(N, H, d, heads, mode)
+        rs = _rs_ok(N, L, H, d, heads, mode)
         blocked = dt == torch.bfloat16 and H == 256 and Cp == 128 and mode not in ("cluster", "rs")
         geom = None if (rs or blocked or mode == "stream") else _cluster_geometry(N, H, d)
         if rs:
@@ -834,6 +938,7 @@ class DualPathRNN(torch.autograd.Function):
             sync = _empty((lib().dtt_lstm_rs_sync_words(N, H),), torch.int32, dev)
             check(lib().dtt_lstm_rs_fwd(ptr(xg), ptr(whh), ptr(y), ptr(gates), ptr(cst), ptr(sync), N, L, heads, H,
                                         d, stream_ptr()), "dtt_lstm_rs_fwd")
+            _note_handoff(dev)
         elif geom is not None:
             # weight-stationary recurrence over a cluster of CUs (lstm_cluster.hip): input projection by GEMM,
             # W_hh resident in LDS, h exchanged through y; activations saved in the blocked layout
@@ -848,6 +953,7 @@ class DualPathRNN(torch.autograd.Function):
             sync = _empty((lib().dtt_lstm_cluster_sync_words(geom[2]),), torch.int32, dev)
             check(lib().dtt_lstm_cluster_fwd(ptr(xg), ptr(whh), ptr(y), ptr(gates), ptr(cst), ptr(sync), N, L, heads, H,
                                              d, stream_ptr()), "dtt_lstm_cluster_fwd")
+            _note_handoff(dev)
         elif blocked:
             # fused input projection, activations saved in the kernels' private blocked layout
             nblk = (N + 31) // 32
@@ -914,6 +1020,7 @@ class DualPathRNN(torch.autograd.Function):
             sync = _empty((lib().dtt_lstm_rs_sync_words(N, H),), torch.int32, dev)
             check(lib().dtt_lstm_rs_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(whhT), ptr(dG), ptr(dcbuf), ptr(dbias),
                                         ptr(sync), N, L, heads, H, d, stream_ptr()), "dtt_lstm_rs_bwd")
+            _note_handoff(dev)
         elif geom is not None:
             N = nslab * heads
             NT = (N + 31) // 32
@@ -924,6 +1031,7 @@ class DualPathRNN(torch.autograd.Function):
             sync = _empty((lib().dtt_lstm_cluster_sync_words(geom[2]),), torch.int32, dev)
             check(lib().dtt_lstm_cluster_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(whhT), ptr(dG), ptr(dcbuf), ptr(dbias),
                                              ptr(sync), N, L, heads, H, d, stream_ptr()), "dtt_lstm_cluster_bwd")
+            _note_handoff(dev)
         elif blocked:
             wpt = _pack_pair("whhpt", w_hh, w_hh_r, dt, False)
             dbias = _zeros_f32((2 * 4 * H,), dev)           # bias gradient accumulated inside the kernel

@@ -137,6 +137,8 @@ class ClipAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from . import ops
+        ops.handoff_poll()                                    # hand-off LSTM kernels of this backward (non-blocking)
         b = self._built
         if b is None or [p.data_ptr() for p in b["params"]] != b["ptrs"]:
             if torch.cuda.is_current_stream_capturing():

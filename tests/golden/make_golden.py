@@ -128,7 +128,7 @@ GRAD_KEYS_AUDIO = [
 
 
 def run_model_case(model, batch, loss_mod, metric_mods, tap_names, grad_keys, extra_inputs=None,
-                   full_taps=True, slices=None):
+                   full_taps=True, slices=None, also_full=()):
     """Forward + PIT loss + backward through the REFERENCE; returns fixture dict."""
     fx = {}
     taps, hs = hook_taps(model, tap_names)
@@ -157,6 +157,8 @@ def run_model_case(model, batch, loss_mod, metric_mods, tap_names, grad_keys, ex
         else:
             fx[f"tap.{n}.abs_sum"] = t.double().abs().sum()
             fx[f"tap.{n}.slice"] = t.reshape(t.shape[0], -1)[:, slices].clone()
+            if n in also_full:
+                fx[f"tap.{n}.full"] = t.half()          # small taps whole (fp16: 2e-4 relative, far below the bars)
     params = dict(model.named_parameters())
     for k in grad_keys:
         g = params[k].grad
@@ -567,8 +569,132 @@ def main_r2():
         json.dump(MANIFEST, f, indent=0, sort_keys=True)
 
 
+def main_r3():
+    """Round-3 fixtures: the two configurations whose end-to-end composition was untested at their own
+    hyper-parameters.  ``python make_golden.py r3 [film_full] [xattn_video]``.
+
+    film_full   -- BASELINE.json configs[2] (cfg3): the reference's REAL ``DTTNetPlusModel`` at
+                   configs/model/dttnet_plus.yaml (g = 32, n_fft 1024, hop 256, 4 IDPs, video_embed_dim = 512,
+                   incl. the YAML-only kwargs freeze_params / unfreeze_params), B = 2 x 2 s, raw lip video
+                   [2, 2, 50, 88, 88], train mode.
+    xattn_video -- configs[3] (cfg4) with RAW video: the reference's ``VideoEncoder`` (built with ``__new__``: its
+                   ``__init__`` downloads a checkpoint) wired into the ``DTTNetVisionModel`` composition of ``main``,
+                   forward through the real ``DTTNetVisionModel.forward`` (model_dttnet_vision.py:79-108), B = 1,
+                   T_v = 50, train mode; gradient slices of the lip encoder's weights included."""
+    torch.set_num_threads(8)
+    _install_reference()
+    import json
+    which = set(sys.argv[2:]) or {"film_full", "xattn_video"}
+    mpath = os.path.join(HERE, "manifest.json")
+    with open(mpath) as f:
+        MANIFEST.update(json.load(f))
+    from src.loss.dttnet_loss import DTTNetLoss
+    from src.loss.pit_loss_wrapper import PITLossWrapper
+    from src.metrics.si_snr_i import SiSnrI
+    from src.metrics.base_metric import PIT_wrapper_inference, PIT_wrapper_training
+    pit = PITLossWrapper(DTTNetLoss())
+    sl = slice(0, None, 4001)
+
+    class _M:
+        def __init__(self, training):
+            self.training = training
+
+        def __call__(self, **b):
+            return (PIT_wrapper_training if self.training else PIT_wrapper_inference)(SiSnrI(), **b)
+
+    metrics = {"SiSnrIPITTraining": _M(True), "SiSnrIPITInference": _M(False)}
+
+    if "film_full" in which:
+        from src.model.DTTNetPlus.model_dttnet import DTTNetPlusModel
+        m = DTTNetPlusModel(g=32, n_sources=2, n_layers=3, n_idp_layers=4, n_heads=2, video_embed_dim=512,
+                            use_checkpoints=False, video_enc_weights_path=None, n_fft=1024, hop_length=256,
+                            freeze_params=None, unfreeze_params=None)
+        sd = m.state_dict()
+        keep = {k: v for k, v in sd.items() if ".encoder.tcn." not in k}
+        MANIFEST["film_full"] = {k: list(v.shape) for k, v in keep.items()}
+        new = {k: (fill_tensor(k, v.shape, 61).to(v.dtype) if k in keep else v) for k, v in sd.items()}
+        m.load_state_dict(new)
+        m.train()
+        batch = make_batch(2, 32000, 1024, 256, seed=62)
+        vid = synth_video(2, 50, seed=63)
+        taps = ["video_encoder", "latent.tfc_tdf", "latent.fusion_block", "latent.idp_modules.0", "latent",
+                "decoder.out_conv"]
+        gk = ["video_encoder.post_processor.weight", "video_encoder.post_processor.bias",
+              "latent.fusion_block.w_gamma_freq.weight", "latent.fusion_block.w_beta_channels.bias",
+              "latent.fusion_block.w_gamma_channels.weight", "encoder.init_conv.weight",
+              "latent.idp_modules.0.tc_rnn.blstm.weight_hh_l0", "latent.idp_modules.3.fc_rnn.fc.weight",
+              "decoder.out_conv.weight"]
+        fx = run_model_case(m, batch, pit, metrics, taps, gk, extra_inputs={"video": vid}, full_taps=False, slices=sl,
+                            also_full=("video_encoder",))
+        fx["weight_checksum"] = weight_checksum({k: new[k] for k in keep})
+        fx["n_trainable"] = sum(p.numel() for p in m.parameters() if p.requires_grad)
+        fx["n_params_no_tcn"] = sum(v.numel() for k, v in keep.items() if v.dtype.is_floating_point and "running" not in k)
+        params = dict(m.named_parameters())
+        assert all(p.grad is None for k, p in params.items() if k.startswith("video_encoder.encoder."))
+        np.savez_compressed(os.path.join(HERE, "film_full.npz"), **npify(fx))
+        print("film_full loss", float(fx["loss"]), "trainable", int(fx["n_trainable"]), "SI-SNRi",
+              float(fx["metric.SiSnrIPITInference"]))
+
+    if "xattn_video" in which:
+        from src.model.DTTNet.modules.encoder import Encoder
+        from src.model.DTTNet.modules.decoder import Decoder
+        from src.model.DTTNet.modules.latent import LatentModule
+        from src.model.DTTNet import model_dttnet_vision as mdv
+        from src.model.VideoAudioFusions.cross_attention_positional import CrossAttentionPositional
+        from src.model.VideoEncoders import resnet_video_encoder as rve
+        from src.model.VideoEncoders.resnet import ResNet, BasicBlock, Swish
+        g_, n_fft, hop = 32, 1024, 256
+        enc = rve.VideoEncoder.__new__(rve.VideoEncoder)          # the constructor's body minus the download
+        torch.nn.Module.__init__(enc)
+        enc.frontend_nout, enc.backend_out = 64, 512
+        enc.trunk = ResNet(BasicBlock, [2, 2, 2, 2], relu_type="swish")
+        enc.frontend3D = torch.nn.Sequential(
+            torch.nn.Conv3d(1, 64, kernel_size=(5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False),
+            torch.nn.BatchNorm3d(64), Swish(),
+            torch.nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1)))
+        m = mdv.DTTNetVisionModel.__new__(mdv.DTTNetVisionModel)
+        torch.nn.Module.__init__(m)
+        m.n_sources, m.n_fft, m.hop_length = 2, n_fft, hop
+        fc = n_fft // 2 + 1
+        m.audio_dim = g_ * 8
+        m.fusion_method = "cross_attention_positional"
+        m.video_encoder = enc
+        m.fusion = CrossAttentionPositional(m.audio_dim, 1024, 2)
+        m.encoder = Encoder(fc, 2, g_, 3, False)
+        m.decoder = Decoder(fc, g_, 2, 3, False)
+        m.latent = LatentModule((fc + 8) // 8, 2, g_ * 16, 4)
+        m.channel_compression = torch.nn.Sequential(torch.nn.Conv2d(m.audio_dim * 2, m.audio_dim, 1),
+                                                    torch.nn.InstanceNorm2d(m.audio_dim), torch.nn.GELU())
+        ck = refill(m, seed=71, name="xattn_video")
+        m.train()
+        batch = make_batch(1, 32000, n_fft, hop, seed=72)
+        vid = synth_video(1, 50, seed=73)
+        taps = ["video_encoder", "fusion", "latent", "channel_compression", "decoder.out_conv"]
+        gk = ["video_encoder.frontend3D.0.weight", "video_encoder.frontend3D.1.weight",
+              "video_encoder.trunk.layer1.0.conv1.weight", "video_encoder.trunk.layer2.0.downsample.0.weight",
+              "video_encoder.trunk.layer3.0.conv1.weight", "video_encoder.trunk.layer4.1.conv2.weight",
+              "video_encoder.trunk.layer4.1.bn2.bias", "fusion.video_proj.0.weight", "fusion.q_audio.weight",
+              "channel_compression.0.weight", "encoder.init_conv.weight", "decoder.out_conv.weight"]
+        fx = run_model_case(m, batch, pit, metrics, taps, gk, extra_inputs={"video": vid}, full_taps=False, slices=sl,
+                            also_full=("video_encoder",))
+        fx["weight_checksum"] = ck
+        fx["n_params"] = sum(p_.numel() for p_ in m.parameters())
+        # BatchNorm running statistics after this ONE train-mode forward (momentum 0.1 from the filled buffers)
+        bufs = dict(m.named_buffers())
+        for k in ("video_encoder.frontend3D.1.running_mean", "video_encoder.trunk.layer4.1.bn2.running_var"):
+            fx["buf." + k] = bufs[k].detach().clone()
+        np.savez_compressed(os.path.join(HERE, "xattn_video.npz"), **npify(fx))
+        print("xattn_video loss", float(fx["loss"]), "params", int(fx["n_params"]), "SI-SNRi",
+              float(fx["metric.SiSnrIPITInference"]))
+
+    with open(mpath, "w") as f:
+        json.dump(MANIFEST, f, indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "r2":
         main_r2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "r3":
+        main_r3()
     else:
         main()

@@ -148,6 +148,7 @@ def test_bench_step_keeps_learning_after_a_host_sync():
     loop.  The non-deep form of lstm_rs_bwd_kernel returned wrong gate gradients from the second replay after such
     a sync on (gradient norm ~1e4 instead of ~15, loss stuck at 4.66 while eager steps reach 3.53: DESIGN finding
     34), because their counters were reset by hipMemsetAsync nodes; a kernel resets them now.  The graph must track eager steps."""
+    from dtt_amd import ops
     losses = {}
     for mode in ("0", "1"):
         w = _bench_workload(mode)
@@ -157,6 +158,7 @@ def test_bench_step_keeps_learning_after_a_host_sync():
         for i in range(5, 24):
             l = w["step"](i)
         torch.cuda.synchronize()
+        ops.handoff_check()                # the hand-off kernels' status words stayed 0 across the sync (finding 34)
         losses[mode] = float(l.detach())
         norm = float(w["opt"]._built["norm"])
         assert norm < 200.0, f"gradient norm {norm} in mode {mode}"
@@ -181,9 +183,12 @@ def test_bench_graph_gradients_match_eager_after_a_host_sync():
         torch.cuda.synchronize()
         return [g.detach().clone() for g in gs.graph_grads]
 
+    from dtt_amd import ops
     before = replay_grads(3)
+    ops.handoff_check()                        # no time-out before ...
     torch.cuda.current_stream().synchronize()
     after = replay_grads(3)
+    ops.handoff_check()                        # ... or after the host-side sync: pins the fix to the mechanism
     gs.reducer.zero_grad()
     for p in gs.params:
         p.grad = None

@@ -300,3 +300,48 @@ def test_full_size_audio_model_scalars(case):
     assert abs(float(r["loss"]) / float(fx["loss"]) - 1) < 1e-4
     v = oracle.pit_metric_inference(oracle.si_snr_i, b["audio"], out["preds"], b["sources"])
     assert abs(float(v) - float(fx["metric.SiSnrIPITInference"])) < 0.05
+
+
+def test_cfg3_and_cfg4_with_raw_video_at_full_size():
+    """Round 3: the oracle's composition of lip encoder + U-Net at BASELINE.json configs[2] / configs[3]
+    hyper-parameters with RAW video, against what the reference's real DTTNetPlusModel / DTTNetVisionModel.forward
+    produced (make_golden.py r3): lip features whole, deep taps by slice, loss, permutation, SI-SNRi."""
+    import torch.nn.functional as F
+    sl = slice(0, None, 4001)
+    # cfg3: ShuffleNetV2 front end (train-mode batch statistics over 2 x 2 x 50 frames) -> post_processor -> FiLM model
+    fx = load_golden("film_full")
+    sd = _sd("film_full", 61)
+    assert abs(weight_checksum(sd) / float(fx["weight_checksum"]) - 1) < 1e-9
+    b = make_batch(2, 32000, 1024, 256, seed=62)
+    taps = {}
+    with torch.no_grad():
+        feats = oracle.lipreading_video_features(sd, "video_encoder.encoder.", synth_video(2, 50, seed=63), training=True)
+        venc = F.linear(feats, sd["video_encoder.post_processor.weight"], sd["video_encoder.post_processor.bias"])
+        assert rel_err(venc, fx["tap.video_encoder.full"].float()) < 5e-4          # stored as fp16
+        out = oracle.dttnet_film_forward(sd, b["spectrogram"], b["phase"], 32000, venc, taps=taps)
+        r = oracle.pit_loss(b["audio"], b["sources"], out["preds"])
+    for n in ("latent.tfc_tdf", "decoder.out_conv"):
+        t = taps[n]
+        assert rel_err(t.reshape(t.shape[0], -1)[:, sl], fx[f"tap.{n}.slice"]) < 2e-3, n
+    assert torch.equal(r["batch_permuts"], fx["batch_permuts"])
+    assert abs(float(r["loss"]) / float(fx["loss"]) - 1) < 1e-4
+    v = oracle.pit_metric_inference(oracle.si_snr_i, b["audio"], out["preds"], b["sources"])
+    assert abs(float(v) - float(fx["metric.SiSnrIPITInference"])) < 0.05
+    # cfg4: ResNet-18 lip encoder (train mode) -> cross-attention fusion -> 2C latent -> compression -> decoder
+    fx = load_golden("xattn_video")
+    sd = _sd("xattn_video", 71)
+    assert abs(weight_checksum(sd) / float(fx["weight_checksum"]) - 1) < 1e-9
+    b = make_batch(1, 32000, 1024, 256, seed=72)
+    taps = {}
+    with torch.no_grad():
+        vf = oracle.resnet18_video_encoder(sd, "video_encoder.", synth_video(1, 50, seed=73), training=True)
+        assert rel_err(vf, fx["tap.video_encoder.full"].float()) < 5e-4
+        out = oracle.dttnet_vision_forward(sd, b["spectrogram"], b["phase"], 32000, vf, "cross_attention_positional", taps=taps)
+        r = oracle.pit_loss(b["audio"], b["sources"], out["preds"])
+    for n in ("fusion", "channel_compression", "decoder.out_conv"):
+        t = taps[n]
+        assert rel_err(t.reshape(t.shape[0], -1)[:, sl], fx[f"tap.{n}.slice"]) < 2e-3, n
+    assert torch.equal(r["batch_permuts"], fx["batch_permuts"])
+    assert abs(float(r["loss"]) / float(fx["loss"]) - 1) < 1e-4
+    v = oracle.pit_metric_inference(oracle.si_snr_i, b["audio"], out["preds"], b["sources"])
+    assert abs(float(v) - float(fx["metric.SiSnrIPITInference"])) < 0.05

@@ -77,6 +77,7 @@ class GraphedTrainStep:
         # plan, 46.5 without: ~400 tiny launches cost ~2 us each inside a graph, the table-driven kernel 0.5 ms)
         if pack_plan is None:
             pack_plan = os.environ.get("DTT_PACK_PLAN", "0") == "1"
+        prev_plan = ops._PLAN.enabled
         ops.weight_plan(pack_plan)
         # handoff_kernels=False (or DTT_GRAPH_HANDOFF=0) keeps the cross-CU hand-off LSTM kernels (H >= 512) out of
         # the recorded step (streaming kernels instead).  They are safe to record since their counters are zeroed by
@@ -84,6 +85,11 @@ class GraphedTrainStep:
         # return wrong gradients (DESIGN finding 34).
         prev_handoff = ops._HANDOFF
         ops.handoff_kernels(handoff_kernels and os.environ.get("DTT_GRAPH_HANDOFF", "1") != "0")
+        # The warm-up passes must leave the training state as they found it: parameters do not move (no optimizer
+        # step), but every train-mode BatchNorm of the lip encoder would advance running_mean / running_var /
+        # num_batches_tracked once per pass -- buffers are snapshotted and put back.  (With world > 1 the warm-up
+        # does issue real collectives: every rank constructs its step at the same point.)
+        saved = [(b, b.detach().clone()) for b in model.buffers()]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # eager warm-up on the side stream (torch's recipe):
@@ -91,6 +97,10 @@ class GraphedTrainStep:
                 self._eager_once(step_opt=False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            for b, v in saved:
+                b.copy_(v)
+        del saved
         if hasattr(optimizer, "prepare"):
             optimizer.prepare()
         ops.finalize_packs()
@@ -110,6 +120,11 @@ class GraphedTrainStep:
             ops.handoff_kernels(prev_handoff)              # only what is RECORDED avoids the hand-off kernels
             if reducer is not None:
                 reducer.pause_hooks(False)
+            if ops._PLAN.enabled != prev_plan:
+                # the process-wide pack-plan switch goes back to what the caller had; the recorded step keeps
+                # writing the plan's persistent buffers on every replay, so they stay alive with this object
+                self._plan_keep = (ops._PLAN.outs, ops._PLAN.pairs, ops._PLAN.table)
+                ops.weight_plan(prev_plan)
         self.graph_grads = [p.grad for p in self.params]   # written in place by every replay: keep them alive
         if self.world == 1:
             self.opt.note_recorded_step()                  # recording executed nothing

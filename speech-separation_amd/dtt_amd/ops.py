@@ -1518,11 +1518,23 @@ class BatchNormAct(torch.autograd.Function):
         return dx, dres, dgb[:, 0].contiguous(), dgb[:, 1].contiguous(), None, None, None, None, None, None
 
 
+def _bn_momentum(bn):
+    """torch's momentum=None means a CUMULATIVE average (factor 1 / num_batches_tracked, a device counter): the
+    reference's lip encoders never use it (resnet.py:36-81: default 0.1), so it is refused rather than silently
+    replaced by 0.1."""
+    if bn.momentum is None:
+        if bn.training and bn.track_running_stats:
+            raise DttError("BatchNorm with momentum=None (cumulative moving average) is not supported by the fused "
+                           "BatchNorm kernels; use a numeric momentum")
+        return 0.0
+    return float(bn.momentum)
+
+
 def batch_norm_act(x, bn, act, res=None):
     """``bn``: an nn.BatchNorm2d (parameter / buffer container; its train()/eval() mode is honoured)."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    mom = 0.1 if bn.momentum is None else bn.momentum
+    mom = _bn_momentum(bn)
     use_batch = bn.training or not bn.track_running_stats
     return BatchNormAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, act)
 
@@ -1595,7 +1607,7 @@ def batch_norm_act_pool(x, bn, act):
     """batch_norm_act followed by MaxPool3x3s2, fused (``bn`` as in batch_norm_act)."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    mom = 0.1 if bn.momentum is None else bn.momentum
+    mom = _bn_momentum(bn)
     use_batch = bn.training or not bn.track_running_stats
     return BatchNormActPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, act)
 

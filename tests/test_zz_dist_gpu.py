@@ -218,19 +218,23 @@ def test_sharded_optimizer_step_two_ranks_match_one_process():
             assert np.linalg.norm(v - rv) <= 2e-4 * np.linalg.norm(rv) + 1e-14, ("exp_avg_sq", name, r)
             covered += m.size
     assert covered == sum(v.size for v in ref["delta"].values())   # the shards tile every parameter exactly once
-    # (3) parameter deltas: on entries with |g| >> eps the first Adam step is -lr * sign(g) (+ lr * wd * p)
+    # (3) parameter deltas: the first AdamW step is -lr * gc / (|gc| + eps) with gc = clip coefficient * g (bias
+    # corrections cancel; the decay term lr * wd * p is ~1e-8): checked where |gc| >> eps, i.e. where rounding-level
+    # differences of g cannot move the result
+    coef = min(1.0, 0.5 / (ref["norm"] + 1e-6))
     moved = 0
     for name, d_ref in ref["delta"].items():
-        g = ref["grad"][name]
-        big = np.abs(g) > 1e-5
+        gc = ref["grad"][name] * coef
+        big = np.abs(gc) > 1e-6
         d = got[0]["delta"][name]
         if big.any():
-            assert np.abs(d[big] - d_ref[big]).max() <= 2e-2 * lr, name
-            assert np.abs(np.abs(d[big]) - lr).max() <= 2e-2 * lr, name         # each such entry moved by ~lr
+            want = -lr * gc[big] / (np.abs(gc[big]) + 1e-8)
+            assert np.abs(d_ref[big] - want).max() <= 2e-2 * lr, name           # the replicated step is AdamW's
+            assert np.abs(d[big] - want).max() <= 2e-2 * lr, name               # ... and so is the sharded one
             moved += 1
-        if np.abs(g).max() > 0:
+        if np.abs(gc).max() > 0:
             assert np.abs(d).max() > 0, name                                    # nothing with a gradient stood still
-    assert moved >= 0.8 * len(ref["delta"])
+    assert moved >= 0.5 * len(ref["delta"]), moved
     # and a single process through the sharded class (world 1: the shard is everything) follows the replicated step
     one = _one_step_probe(0, 1, True)
     assert abs(one["norm"] - ref["norm"]) <= 1e-5 * abs(ref["norm"])

@@ -374,7 +374,7 @@ def _time_lstm(ops, B, g, seconds, dt, dev):
     xg = (torch.randn(R, 8 * H, device=dev) * 0.5).to(dt)
     whh = torch.randn(2, 4 * H, H, device=dev) / H ** 0.5
     y = torch.empty(R, 2 * H, device=dev, dtype=dt)
-    rs = ops._rs_ok(N, H, d, heads, "auto")
+    rs = ops._rs_ok(N, L, H, d, heads, "auto")
     geom = None if rs else ops._cluster_geometry(N, H, d)
     if rs:
         NT = (N + 31) // 32

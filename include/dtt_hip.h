@@ -63,7 +63,8 @@ typedef struct DttGemm {
      * are structural zeros on average); 1 + 2*pf + pt = only the output pixels (fo, to) with
      * fo%2 == pf, to%2 == pt: M = B * ceil((cFo-pf)/2) * ceil((cTo-pt)/2), K = (pf?2:1)*(pt?2:1)*cCi
      * with the taps kh in (pf ? {0,2} : {1}), kw likewise; C rows are the pixels' rows of the full
-     * [B][cFo][cTo] output (c_ms = row stride of that tensor)                                  */
+     * [B][cFo][cTo] output (c_ms = row stride of that tensor); a residual R is indexed by the COMPACT
+     * GEMM row m (the phase's own [B][Fp][Tp] pixel order), r_ms its row stride                 */
     int32_t cphase;
     int32_t reserved_;
     /* optional scratch for split-K (atomic = 1) products: with ws_bytes >= dtt_gemm_ws_bytes(p) the k-splits store
@@ -84,6 +85,10 @@ typedef struct DttGemm {
 int dtt_gemm(const DttGemm* p, void* stream);
 /* bytes of workspace with which dtt_gemm(p) would take the store-and-sum split-K path; 0: it has no use for one */
 int64_t dtt_gemm_ws_bytes(const DttGemm* p);
+/* Diagnostic: dtt_gemm calls of this process that ran on the LDS-DMA tile kernels of gemmx.hip (bf16, k-contiguous
+ * or stride-1 3x3 conv-row A operand, M >= 2048, N >= 64: block_tfc_tdf.py:12-17 convs and data gradients at
+ * C >= 128, the ResNet-18 trunk's stride-1 convs, large Linears).  DTT_GEMMX=0 disables them. */
+long long dtt_gemmx_launches(void);
 
 /* Dedicated 3x3 stride-1 'same' conv on channels-last (block_tfc_tdf.py:12-32): LDS input
  * patches shared by the nine taps; wp = [Co][9][Ci]; optional fused residual and fused
@@ -102,6 +107,10 @@ int dtt_conv3x3_wgrad(const void* dy, const void* x, float* dw, int B, int F, in
 int64_t dtt_conv3x3_wgrad_ws_bytes(int B, int F, int T, int Ci, int Co);
 int dtt_conv3x3_wgrad_ws(const void* dy, const void* x, float* dw, void* ws, int64_t ws_bytes, int B, int F, int T,
                          int Ci, int Co, int dtype, void* stream);
+/* ... with dw in nn.Conv2d.weight's own layout [Co][Ci][3][3] (block_tfc_tdf.py:12-17: the parameter whose .grad it
+ * becomes) instead of [Co][9][Ci]: no permute copy on the caller's side. */
+int dtt_conv3x3_wgrad_ws_param(const void* dy, const void* x, float* dw, void* ws, int64_t ws_bytes, int B, int F, int T,
+                               int Ci, int Co, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * InstanceNorm2d(affine=False, eps) + exact GELU on channels-last tensors

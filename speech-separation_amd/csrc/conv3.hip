@@ -545,8 +545,10 @@ __global__ __launch_bounds__(256, CT == 32 ? 2 : 1) void conv3x3_wgrad_kernel(Wg
 }
 
 // dw[e] = sum over the splits' slabs (overwrites dw).  256 threads = 16 float4 columns x 16 slab groups.
+// Ci > 0: dw is written in the PARAMETER's layout [Co][Ci][3][3] (nn.Conv2d.weight) instead of the kernels'
+// [Co][9][Ci]: the permute copy per convolution that the caller would otherwise make disappears.
 __global__ __launch_bounds__(256) void wg3_sum_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t quads,
-                                                      int nslab) {
+                                                      int nslab, int Ci) {
     __shared__ float4 sh[16][17];
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int64_t qd = (int64_t)blockIdx.x * 16 + c;
@@ -562,7 +564,14 @@ __global__ __launch_bounds__(256) void wg3_sum_kernel(const float* __restrict__ 
         float4 t = sh[0][c];
 #pragma unroll
         for (int i = 1; i < 16; ++i) { const float4 v = sh[i][c]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-        *reinterpret_cast<float4*>(dw + qd * 4) = t;
+        if (Ci <= 0) {
+            *reinterpret_cast<float4*>(dw + qd * 4) = t;
+        } else {
+            const int64_t flat = qd * 4, row = flat / Ci;             // row = co * 9 + tap, 4 | Ci
+            const int ci = (int)(flat - row * Ci), tap = (int)(row % 9);
+            float* d = dw + ((row / 9) * Ci + ci) * 9 + tap;
+            d[0] = t.x; d[9] = t.y; d[18] = t.z; d[27] = t.w;
+        }
     }
 }
 
@@ -728,7 +737,8 @@ WgGeom wg_geom(int B, int F, int T, int Ci, int Co) {
     return g;
 }
 
-int wgrad_launch(const void* dy, const void* x, float* dw, float* ws, int B, int F, int T, int Ci, int Co, void* stream) {
+int wgrad_launch(const void* dy, const void* x, float* dw, float* ws, int B, int F, int T, int Ci, int Co, void* stream,
+                 bool param_layout = false) {
     const WgGeom g = wg_geom(B, F, T, Ci, Co);
     Wg3P p{dy, x, dw, B, F, T, Ci, Co, (F + TH - 1) / TH, (T + TW - 1) / TW, g.tpw, ws};
     if (g.c32) {
@@ -747,7 +757,8 @@ int wgrad_launch(const void* dy, const void* x, float* dw, float* ws, int B, int
     }
     if (p.ws) {
         const int64_t quads = (int64_t)Co * 9 * Ci / 4;
-        hipLaunchKernelGGL(wg3_sum_kernel, dim3((unsigned)((quads + 15) / 16)), dim3(256), 0, ST, ws, dw, quads, g.nsplit);
+        hipLaunchKernelGGL(wg3_sum_kernel, dim3((unsigned)((quads + 15) / 16)), dim3(256), 0, ST, ws, dw, quads, g.nsplit,
+                           param_layout ? Ci : 0);
     }
     DTT_LAUNCH_CHECK();
     return 0;
@@ -781,4 +792,15 @@ extern "C" int dtt_conv3x3_wgrad_ws(const void* dy, const void* x, float* dw, vo
     DTT_CHECK(ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
               "dtt_conv3x3_wgrad_ws: workspace of %lld bytes needed", (long long)need);
     return wgrad_launch(dy, x, dw, reinterpret_cast<float*>(ws), B, F, T, Ci, Co, stream);
+}
+// As dtt_conv3x3_wgrad_ws with dw written in nn.Conv2d.weight's own layout [Co][Ci][3][3].
+extern "C" int dtt_conv3x3_wgrad_ws_param(const void* dy, const void* x, float* dw, void* ws, int64_t ws_bytes, int B, int F,
+                                          int T, int Ci, int Co, int dtype, void* stream) {
+    DTT_CHECK(dtype == 1, "dtt_conv3x3_wgrad_ws_param: bf16 only (fp32 goes through dtt_gemm)");
+    DTT_CHECK(B > 0 && F > 0 && T > 0 && Ci % 32 == 0 && Co % 32 == 0, "dtt_conv3x3_wgrad_ws_param: unsupported Ci=%d Co=%d", Ci, Co);
+    const int64_t need = dtt_conv3x3_wgrad_ws_bytes(B, F, T, Ci, Co);
+    DTT_CHECK(need > 0, "dtt_conv3x3_wgrad_ws_param: no workspace form for Ci=%d Co=%d (use dtt_conv3x3_wgrad)", Ci, Co);
+    DTT_CHECK(ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+              "dtt_conv3x3_wgrad_ws_param: workspace of %lld bytes needed", (long long)need);
+    return wgrad_launch(dy, x, dw, reinterpret_cast<float*>(ws), B, F, T, Ci, Co, stream, true);
 }

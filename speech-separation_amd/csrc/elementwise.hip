@@ -141,7 +141,8 @@ __global__ __launch_bounds__(NT) void bcat_fwd_kernel(const T* __restrict__ x, c
     }
 }
 
-// dx[b,f,t,c] = dout[...,c] + dtok[b,t,c]/F ; denh[b,t,c] = sum_f dout[...,C+c]
+// dx[b,f,t,c] = dout[...,c] + dtok[b,t,c]/F ; denh[b,t,c] = sum_f dout[...,C+c]   (dx or denh may be NULL: that half
+// of the work is skipped -- the two halves run as two calls when dtok only exists after denh has been consumed)
 template <typename T>
 __global__ __launch_bounds__(NT) void bcat_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ dtok,
                                                       T* __restrict__ dx, float* __restrict__ denh, int B, int F,
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(NT) void bcat_bwd_kernel(const T* __restrict__ dout
         float s = 0.f, dt = dtok ? dtok[i] * invF : 0.f;
         for (int f = 0; f < F; ++f) {
             int64_t pix = ((int64_t)b * F + f) * Tn + t;
-            s += ldf(dout + pix * 2 * C + C + c);
-            stf(dx + pix * C + c, ldf(dout + pix * 2 * C + c) + dt);
+            if (denh) s += ldf(dout + pix * 2 * C + C + c);
+            if (dx) stf(dx + pix * C + c, ldf(dout + pix * 2 * C + c) + dt);
         }
         if (denh) denh[i] = s;
     }

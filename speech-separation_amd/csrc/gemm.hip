@@ -756,7 +756,7 @@ template <typename T> int dispatch_fast(const DttGemm& p, hipStream_t st) {
     if (p.a_mode == 1) {
         // implicit-GEMM conv rows (stride-2 / transposed convs): weights k-contiguous
         if (p.b_mode != 0 || p.batch != 1 || p.b_ks != 1 || p.b_ns % E != 0 || p.cCi % E != 0 || p.c_ns != 1 ||
-            (p.R && p.r_ns != 1) || (p.atomic && p.bias_mode) || (p.R && p.cphase))
+            (p.R && p.r_ns != 1) || (p.atomic && p.bias_mode))
             return 1;
         if ((reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.B) & 15)) return 1;
         return dispatch_fast_tile<T, OP_CONV, OP_KC>(p, st);
@@ -815,6 +815,7 @@ template <typename T> int dispatch(const DttGemm& p, hipStream_t st) {
 }  // namespace
 
 int dtt_gemm256_try(const DttGemm& p, hipStream_t st);   // gemm256.hip
+int dtt_gemmx_try(const DttGemm& p, hipStream_t st);     // gemmx.hip
 int64_t dtt_gemm256_ws_bytes(const DttGemm& p);
 
 extern "C" int64_t dtt_gemm_ws_bytes(const DttGemm* p) { return p ? dtt_gemm256_ws_bytes(*p) : 0; }
@@ -831,7 +832,9 @@ extern "C" int dtt_gemm(const DttGemm* pp, void* stream) {
     DTT_CHECK((int64_t)p.batch * p.splitk <= 65535, "dtt_gemm: grid.y too large");
     if (p.a_mode == 1 && p.cphase) {
         const int pf = (p.cphase - 1) >> 1, pt = (p.cphase - 1) & 1;
-        DTT_CHECK(p.cphase >= 1 && p.cphase <= 4 && p.ctrans && p.cstride == 2 && !p.atomic && p.R == nullptr,
+        // (a residual R is indexed by the COMPACT GEMM row -- [M = B * Fp * Tp][N], the phase's own pixel order --
+        // while C is scattered to the phase's pixels of the full plane: both epilogues do exactly that)
+        DTT_CHECK(p.cphase >= 1 && p.cphase <= 4 && p.ctrans && p.cstride == 2 && !p.atomic,
                   "dtt_gemm: cphase needs a plain-store transposed stride-2 conv");
         DTT_CHECK(p.K == (pf ? 2 : 1) * (pt ? 2 : 1) * p.cCi &&
                       p.M == p.cB * ((p.cFo - pf + 1) / 2) * ((p.cTo - pt + 1) / 2),
@@ -861,6 +864,8 @@ extern "C" int dtt_gemm(const DttGemm* pp, void* stream) {
     if (p.b_mode == 2) DTT_CHECK(p.sh_heads > 0 && p.sh_L > 0 && p.b_ns == 1, "dtt_gemm: bad shift params");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc = dtt_gemm256_try(p, st);
+    if (rc != 1) return rc;
+    rc = dtt_gemmx_try(p, st);
     if (rc != 1) return rc;
     rc = p.dtype == 1 ? dispatch_fast<bf16>(p, st) : dispatch_fast<float>(p, st);
     if (rc != 1) return rc;

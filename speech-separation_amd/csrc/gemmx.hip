@@ -1,0 +1,324 @@
+// gemm256's LDS-DMA skeleton (gemm256.hip) with the workgroup tile as a template parameter and a GATHERED A operand:
+// the implicit-GEMM rows of a 3x3 / stride-1 / pad-1 convolution on a channels-last tensor (m = output pixel,
+// k = tap * Ci + ci), i.e. every such Conv2d of the path and its data gradient (block_tfc_tdf.py:12-32, the ResNet-18
+// trunk of the lip encoder VideoEncoders/resnet.py:26-81), next to the plain k-contiguous products (nn.Linear,
+// latent.py:93-96).
+//
+// What is kept from gemm256: both operands go global -> LDS by LDS-DMA (no staging registers, no ds_write) into NST
+// stages of k-steps of 32, one raw s_barrier + counted vmcnt per k-step, the [row][64 B] image with the swizzle on
+// the SOURCE side, wave tile 128 x 64 (4 x 2 MFMA 32x32x16, six ds_read_b128 per eight MFMAs), fragment reads in
+// inline asm double-buffered across the barrier.  What is new:
+//   * WM x WN waves per workgroup (tile 128 WM x 64 WN): 256 x 256 (8 waves, one workgroup per CU), 256 x 128,
+//     128 x 256 (4 waves), 128 x 128 (2 waves), 256 x 64 (2 waves) -- the implicit GEMMs of the step have N = Co =
+//     64 ... 512 and M = 14 400 ... 260 000 pixels, where a fixed 256 x 256 tile leaves CUs idle or a last round
+//     nearly empty;
+//   * the conv gather is ONE select per DMA instruction: a lane's A piece always belongs to the same output pixel,
+//     whose nine taps are the pixel's own row of x shifted by a wave-uniform offset ((kh-1) T + (kw-1)) Ci, or the
+//     16-byte zero page where the tap falls outside the image (a 9-bit mask per lane, computed once).  No patch, no
+//     halo: a tile is 256 consecutive pixels of the flattened [B F T] axis, so images of 3 x 3 ... 22 x 22 pixels
+//     (the lip encoder's layers) or 65 x 16 (the latent) fill tiles as well as 257 x 63.  The price is that x is
+//     read nine times from L2 / LDS-DMA (once from HBM); the 64 B/clk/CU vector-memory path carries
+//     (BM + BN) 64 B per k-step against BM BN / 64 clocks of MFMA: 0.75 at 256 x 128, 0.5 at 256 x 256.
+// Epilogue as gemm256: bias[n], residual, bf16 / fp32 store through an LDS slab per wave.
+#include <algorithm>
+#include <cstdlib>
+#include "common.h"
+#include "../../include/dtt_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int BK = 32;
+constexpr int SLAB_W = 64 + 4;                             // epilogue slab row (floats)
+
+struct XFrag { s16x8_t v[6]; };
+__device__ __forceinline__ void x_read(XFrag& f, const unsigned (&a)[6]) {
+    asm volatile(
+        "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\t"
+        "ds_read_b128 %3, %9\n\tds_read_b128 %4, %10\n\tds_read_b128 %5, %11"
+        : "=&v"(f.v[0]), "=&v"(f.v[1]), "=&v"(f.v[2]), "=&v"(f.v[3]), "=&v"(f.v[4]), "=&v"(f.v[5])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]));
+}
+template <int N>
+__device__ __forceinline__ void x_fence(XFrag& f) {
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]), "+v"(f.v[3]), "+v"(f.v[4]), "+v"(f.v[5]) : "n"(N));
+}
+
+// WM x WN waves of 128 x 64; CONV: A = 3x3 / stride 1 / pad 1 conv rows of x [cB][cFi][cTi][cCi] (cCi % 32 == 0);
+// else A [M][K] k-contiguous.  B [N][K] k-contiguous, C [M][N] n-contiguous.  NST stages.
+template <int WM, int WN, bool CONV, int NST>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemmx_kernel(const DttGemm p) {
+    constexpr int BM = 128 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    constexpr int NA = BM / 16 / NW, NB = BN / 16 / NW;    // DMA wave-instructions (16 rows of 64 B each) per wave
+    constexpr int NDMA = NA + NB;
+    static_assert(NA * NW * 16 == BM && NB * NW * 16 == BN && NA >= 1 && NB >= 1, "tile / wave split");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN, ntile = gridDim.x;
+    int tile = blockIdx.x;
+    {   // XCD-aware order: consecutive logical tiles (which share an A panel) run on one XCD
+        const int per = ntile / 8;
+        if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
+    }
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    const int KT = p.K / BK;
+
+    // ---- DMA sources.  Wave-instruction j of a wave fills 16 rows of the A (B) image: row r = (wave * NA + j) * 16
+    //      + lane / 4, LDS position lane % 4 holds the SOURCE piece (lane % 4) ^ ((r >> 2) & 3).
+    const bf16* pa[NA];
+    const bf16* pb[NB];
+    unsigned vm[NA];                                       // CONV: taps of the lane's pixel that lie inside the image
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int row = (wave * NA + j) * 16 + (lane >> 2), piece = (lane & 3) ^ ((row >> 2) & 3);
+        const int gm = min(m0 + row, p.M - 1);
+        if constexpr (CONV) {
+            const int t = gm % p.cTi, f = (gm / p.cTi) % p.cFi;
+            unsigned m = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ff = f + tap / 3 - 1, tt = t + tap % 3 - 1;
+                m |= (ff >= 0 && ff < p.cFi && tt >= 0 && tt < p.cTi) ? (1u << tap) : 0u;
+            }
+            vm[j] = m;
+            pa[j] = A + (int64_t)gm * p.cCi + piece * 8;
+        } else {
+            vm[j] = 0;
+            pa[j] = A + (int64_t)gm * p.a_ms + piece * 8;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = (wave * NB + j) * 16 + (lane >> 2), piece = (lane & 3) ^ ((row >> 2) & 3);
+        pb[j] = B + (int64_t)min(n0 + row, p.N - 1) * p.b_ns + piece * 8;
+    }
+    // Every call issues exactly NDMA wave-instructions (the waits below count them); past the last k-step it re-reads
+    // that step into a stage nobody will read.
+    const int cpt = CONV ? p.cCi / BK : 1;                 // k-steps per tap
+    int nk = 0, tap = 0, sub = 0;                          // k-step the sources point at = min(nk, KT - 1)
+    int64_t aoff = CONV ? -((int64_t)p.cTi + 1) * p.cCi : 0;   // element offset of the current (tap, chunk) / k-step
+    auto issue = [&](int stage) {
+        unsigned char* sa = smem + stage * STAGE_BYTES + (wave * NA) * 1024;
+        unsigned char* sb = smem + stage * STAGE_BYTES + BM * BK * 2 + (wave * NB) * 1024;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const bf16* src = pa[j] + aoff;
+            if constexpr (CONV) src = ((vm[j] >> tap) & 1u) ? src : reinterpret_cast<const bf16*>(&dtt_zero16);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + j * 1024), 16, 0, 0);
+        }
+        const int64_t boff = (int64_t)min(nk, KT - 1) * BK;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(pb[j] + boff), (lptr_t)(sb + j * 1024), 16, 0, 0);
+        if (nk < KT - 1) {
+            if constexpr (CONV) {
+                if (++sub == cpt) {                        // next tap: (kh, kw) -> pixel shift (kh-1) T + (kw-1)
+                    sub = 0; ++tap;
+                    const int kh = tap / 3, kw = tap - kh * 3;
+                    aoff = ((int64_t)(kh - 1) * p.cTi + (kw - 1)) * p.cCi;
+                } else {
+                    aoff += BK;
+                }
+            } else {
+                aoff += BK;
+            }
+        }
+        ++nk;
+    };
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: row * 64 bytes + ((2 s + lh) ^ swz(row)) * 16
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+    unsigned o0[6], o1[6], ad0[6], ad1[6];                 // byte offsets of the lane's pieces for k 0..15 / 16..31
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int row = wm * 128 + a * 32 + lr, sw = (row >> 2) & 3;
+        o0[a] = row * 64 + ((lh ^ sw) << 4); o1[a] = row * 64 + (((2 + lh) ^ sw) << 4);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int row = wn * 64 + b * 32 + lr, sw = (row >> 2) & 3;
+        o0[4 + b] = BM * BK * 2 + row * 64 + ((lh ^ sw) << 4); o1[4 + b] = BM * BK * 2 + row * 64 + (((2 + lh) ^ sw) << 4);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { ad0[a] = lds0 + o0[a]; ad1[a] = lds0 + o1[a]; }
+
+    // pipeline: see gemm256.hip.  D = NST - 1 k-steps of DMA lead; `vmcnt((D - 2) NDMA)`: this wave's pieces of
+    // step i + 1 have landed; barrier: everyone's have, and everyone is past its last read of step i - 1, whose
+    // stage the DMA of step i + D refills.
+    constexpr int D = NST - 1;
+    static_assert(D >= 2, "stages");
+#define GX_SYNC(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(N) : "memory")
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d);
+    GX_SYNC((D - 1) * NDMA);
+    int cs = 0, fs = D;
+    XFrag f0, f1;
+#define GX_MMA(F) do { _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b) \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, F.v[a]), __builtin_bit_cast(bf16x8_t, F.v[4 + b]), acc[a][b], 0, 0, 0); } while (0)
+    x_read(f0, ad0);
+    for (int i = 0; i < KT; ++i) {
+        x_read(f1, ad1);
+        x_fence<6>(f0);
+        GX_MMA(f0);
+        GX_SYNC((D - 2) * NDMA);
+        issue(fs);
+        fs = fs + 1 == NST ? 0 : fs + 1;
+        cs = cs + 1 == NST ? 0 : cs + 1;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { ad0[a] = lds0 + cs * STAGE_BYTES + o0[a]; ad1[a] = lds0 + cs * STAGE_BYTES + o1[a]; }
+        x_read(f0, ad0);                                   // (past the last step: a stage of re-read data, unused)
+        x_fence<6>(f1);
+        GX_MMA(f1);
+    }
+    x_fence<0>(f0);
+#undef GX_MMA
+#undef GX_SYNC
+    // the trailing (dummy) DMAs still write LDS: drain them before the slab overlays the stages / the kernel ends
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- epilogue: one 32 x 64 fp32 slab per wave at a time through LDS, 16-byte stores along n
+    float* slab = reinterpret_cast<float*>(smem) + wave * 32 * SLAB_W;
+    const bf16* R = reinterpret_cast<const bf16*>(p.R);
+    const bool f32out = p.out_f32 != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gn = n0 + wn * 64 + j * 32 + lr;
+            const float bv = (p.bias_mode == 1 && gn < p.N) ? p.bias[gn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLAB_W + j * 32 + lr] = acc[i][j][r] * p.alpha + bv;
+        }
+        // (wave-private slab: LDS operations of one wave stay in order, no barrier)
+        const int gm0 = m0 + wm * 128 + i * 32, gn0 = n0 + wn * 64;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = lane + it * 64, row = idx >> 3, ch = idx & 7;          // 8 chunks of 8 outputs per row
+            const int gm = gm0 + row, gn = gn0 + ch * 8;
+            if (gm >= p.M || gn >= p.N) continue;
+            float v[8];
+            const float4 s0 = *reinterpret_cast<const float4*>(slab + row * SLAB_W + ch * 8);
+            const float4 s1 = *reinterpret_cast<const float4*>(slab + row * SLAB_W + ch * 8 + 4);
+            v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
+            if (R) {
+                const Vec16<bf16> rv = ld16<bf16>(R + (int64_t)gm * p.r_ms + gn);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv.get(e);
+            }
+            if (f32out) {
+                float* dst = reinterpret_cast<float*>(p.C) + (int64_t)gm * p.c_ms + gn;
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                Vec16<bf16> ov;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) ov.set2(e, v[e], v[e + 1]);
+                st16<bf16>(reinterpret_cast<bf16*>(p.C) + (int64_t)gm * p.c_ms + gn, ov);
+            }
+        }
+    }
+}
+
+long long g_gemmx_launches = 0;
+
+int gemmx_mode() {      // DTT_GEMMX: 0 off, 1 on (default), 2 = also take shapes the other kernels were tuned for (A/B)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("DTT_GEMMX"); on = e ? atoi(e) : 1; }
+    return on;
+}
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int WM, int WN, bool CONV, int NST>
+void launch_x(const DttGemm& p, hipStream_t st) {
+    constexpr int BM = 128 * WM, BN = 64 * WN;
+    constexpr int sm = NST * (BM + BN) * BK * 2;
+    static_assert(sm >= WM * WN * 32 * SLAB_W * 4, "the epilogue slabs overlay the stages");
+    static bool attr = false;
+    auto k = gemmx_kernel<WM, WN, CONV, NST>;
+    if (!attr) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, sm); attr = true; }
+    const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, p);
+}
+
+}  // namespace
+
+// launches of gemmx_kernel by this process so far (tests: the shape under test really ran here)
+extern "C" long long dtt_gemmx_launches(void) { return g_gemmx_launches; }
+
+// 1: not covered (the caller goes on to the other kernels); 0 / negative as dtt_gemm
+int dtt_gemmx_try(const DttGemm& p, hipStream_t st) {
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const int mode = gemmx_mode();
+    if (!mode || p.dtype != 1 || p.batch != 1 || p.act || p.c_ns != 1 || p.K % BK || p.splitk != 1 || p.atomic ||
+        p.b_mode || p.b_ks != 1 || p.b_ns % 8 || p.N % 8 || p.c_ms % 8 || p.bias_mode > 1 || !al(p.A) || !al(p.B) ||
+        !al(p.C) || (p.R && (p.r_ns != 1 || p.r_ms % 8 || !al(p.R))) || p.K < 3 * BK)
+        return 1;
+    const bool conv = p.a_mode == 1;
+    if (conv) {
+        if (p.cstride != 1 || p.ctrans || p.cphase || p.cKW || p.cCi % BK || p.K != 9 * p.cCi || p.cFo != p.cFi ||
+            p.cTo != p.cTi || p.M != p.cB * p.cFi * p.cTi)
+            return 1;
+    } else if (p.a_mode || p.a_ks != 1 || p.a_ms % 8) {
+        return 1;
+    }
+    if (p.N < 64 || p.M < 2048) return 1;
+    // Tile choice.  Candidates (BM, BN, workgroups per CU by LDS, quality): a smaller tile moves more operand bytes
+    // per flop through the CU's vector-memory path, a bigger one fills the last round of workgroups worse (or leaves
+    // CUs idle).  score = useful fraction of the rounds the launch takes x quality.
+    struct Cand { int bm, bn, per_cu; double q; int id; };
+    static const Cand cands[] = {{256, 256, 1, 1.00, 0}, {128, 256, 2, 0.90, 1}, {256, 128, 2, 0.90, 2},
+                                 {128, 128, 3, 0.80, 3}, {256, 64, 2, 0.65, 4}};
+    const int cus = num_cus();
+    int best = -1;
+    double best_score = 0.0;
+    for (const Cand& c : cands) {
+        if (c.bn > 64 && p.N < c.bn - 32) continue;        // (a 256-wide tile on N = 128 would be half empty)
+        if (c.bn == 64 && p.N > 64) continue;
+        if (c.bn == 128 && p.N >= 256 && p.N % 256 == 0 && c.bm == 256) continue;
+        const int64_t t = (int64_t)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
+        const int64_t slots = (int64_t)cus * c.per_cu, r = (t + slots - 1) / slots;
+        const double nfill = (double)p.N / (double)(((p.N + c.bn - 1) / c.bn) * c.bn);
+        const double score = (double)t / (double)(r * slots) * c.q * nfill;
+        if (score > best_score) { best_score = score; best = c.id; }
+    }
+    if (best < 0) return 1;
+    if (best == 4 && mode < 2 && !conv) return 1;
+#define GX_LAUNCH(WMV, WNV, NSTV) do { if (conv) launch_x<WMV, WNV, true, NSTV>(p, st); else launch_x<WMV, WNV, false, NSTV>(p, st); } while (0)
+    switch (best) {
+        case 0: GX_LAUNCH(2, 4, 4); break;
+        case 1: GX_LAUNCH(1, 4, 3); break;
+        case 2: GX_LAUNCH(2, 2, 3); break;
+        case 3: GX_LAUNCH(1, 2, 3); break;
+        default: GX_LAUNCH(2, 1, 3); break;
+    }
+#undef GX_LAUNCH
+    ++g_gemmx_launches;
+    DTT_LAUNCH_CHECK();
+    return 0;
+}

@@ -84,10 +84,12 @@ class CrossAttentionPositional(nn.Module):
         return a * lin(a, self.audio_gate[0].weight, self.audio_gate[0].bias, True)
 
     def forward(self, audio_features, video_features):
-        tok = ops.FreqMeanTokens.apply(audio_features)                 # [B,T,C] fp32
+        # audio_features feeds the token mean and the concat: one pass forms the sum of their gradients (ops.GradSlot)
+        slot = ops.new_slot(audio_features)
+        tok = ops.FreqMeanTokens.apply(audio_features, slot)           # [B,T,C] fp32
         with torch.autocast("cuda", enabled=False):
             enh = self._tokens(tok, video_features)
-        return ops.BroadcastConcat.apply(audio_features, enh)
+        return ops.BroadcastConcat.apply(audio_features, enh, slot)
 
 
 class TemporalAligner(nn.Module):

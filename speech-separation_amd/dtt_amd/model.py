@@ -58,15 +58,18 @@ class TFC_TDF_Block(nn.Module):
 
     def forward(self, x, name=""):
         h = x
+        # x feeds conv1[0] and skip_conv: their two partial gradients meet inside conv1[0]'s data-gradient kernel
+        # (ops.GradSlot) instead of an autograd add over the whole tensor
+        slot = ops.new_slot(x)
         for i in range(3):
             c = self.conv1[i][0]
-            h = ops.ConvNormGelu.apply(h, c.weight, c.bias, "s1", None)
+            h = ops.ConvNormGelu.apply(h, c.weight, c.bias, "s1", None, slot if i == 0 else None)
             _Tap.put(f"{name}.conv1.{i}", h)
         h = ops.TDF.apply(h, self.fc[0].weight, self.fc[0].bias, self.fc[1].weight, self.fc[1].bias)
         for i in range(3):
             c = self.conv2[i][0]
             h = ops.ConvNormGelu.apply(h, c.weight, c.bias, "s1", None)
-        out = ops.ConvAdd.apply(x, self.skip_conv.weight, self.skip_conv.bias, h)
+        out = ops.ConvAdd.apply(x, self.skip_conv.weight, self.skip_conv.bias, h, slot)
         _Tap.put(name, out)
         return out
 
@@ -79,9 +82,9 @@ class DownSamplingBlock(nn.Module):
         self.downsampling = nn.Sequential(nn.Conv2d(in_channels, 2 * in_channels, 3, stride=2, padding=1),
                                           nn.InstanceNorm2d(2 * in_channels), nn.GELU())
 
-    def forward(self, x):
+    def forward(self, x, slot=None):
         c = self.downsampling[0]
-        return ops.ConvNormGelu.apply(x, c.weight, c.bias, "down", None)
+        return ops.ConvNormGelu.apply(x, c.weight, c.bias, "down", None, slot)
 
 
 class UpSamplingBlock(nn.Module):
@@ -106,7 +109,11 @@ class EncoderBlock(nn.Module):
 
     def forward(self, x, name=""):
         skip = self.tfc_tdf(x, name + ".tfc_tdf")
-        out = self.downsampling(skip)
+        # the skip feeds this down-sampling conv and, much later, the decoder's multiply (decoder.py:43): the slot
+        # rides on the tensor object so that DecoderBlock finds it (ops.GradSlot)
+        slot = ops.new_slot(skip)
+        skip._dtt_grad_slot = slot
+        out = self.downsampling(skip, slot)
         _Tap.put(name, out)
         return out, skip
 
@@ -222,7 +229,7 @@ class DecoderBlock(nn.Module):
         out = self.upsampling(x, (skip.shape[1], skip.shape[2]))
         _Tap.put(name + ".upsampling", out)
         out = self.tfc_tdf(out, name + ".tfc_tdf")
-        out = ops.MulSkip.apply(out, skip)
+        out = ops.MulSkip.apply(out, skip, getattr(skip, "_dtt_grad_slot", None))
         _Tap.put(name, out)
         return out
 

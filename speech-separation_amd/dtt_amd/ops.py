@@ -60,14 +60,16 @@ def reset_zero_arena():
 # --------------------------------------------------------------------------- #
 # thin wrappers over the C entry points
 # --------------------------------------------------------------------------- #
-def conv_gemm(x, wp, bias, out, geom, res=None, phases=False):
+def conv_gemm(x, wp, bias, out, geom, res=None, phases=False, res00=None):
     """Implicit-GEMM 3x3 conv: x [B,Fi,Ti,Ci] -> out [B,Fo,To,Co]; wp [Co][9*Ci].  phases: force the four-parity
     form of a transposed conv (wins once a phase's K = Ci .. 4 Ci is long: the lip encoder's stride-2 convs)."""
     Co = wp.shape[0]
     if geom["ctrans"] and res is None and (Co <= 32 or phases):
         # measured: the four parity GEMMs win only while the tile is narrow (Co = 32: 499 vs 542 us at
         # full resolution); at Co >= 64 the K of a phase is too short and one 9-tap GEMM is faster
-        return conv_gemm_transposed(x, wp, bias, out, geom)
+        return conv_gemm_transposed(x, wp, bias, out, geom, res00=res00)
+    if res00 is not None:
+        raise DttError("conv_gemm: a compact even-pixel residual needs the four-parity transposed form")
     M = geom["cB"] * geom["cFo"] * geom["cTo"]
     kw = dict(A=x, B=wp, C=out, M=M, N=Co, K=9 * geom["cCi"], a_ms=0, a_ks=1, b_ks=1, b_ns=wp.shape[1],
               c_ms=Co, c_ns=1, dtype=_dt(x), a_mode=1, **geom)
@@ -78,10 +80,12 @@ def conv_gemm(x, wp, bias, out, geom, res=None, phases=False):
     gemm_raw(**kw)
 
 
-def conv_gemm_transposed(x, wp, bias, out, geom):
+def conv_gemm_transposed(x, wp, bias, out, geom, res00=None):
     """Transposed 3x3 stride-2 conv (ConvTranspose2d forward / data gradient of the stride-2 conv) as
     four GEMMs, one per output parity (fo%2, to%2): each touches only the taps that can reach such
-    a pixel (1, 2, 2 and 4 of the 9), so no structural zeros are multiplied.  wp [Co][9*Ci]."""
+    a pixel (1, 2, 2 and 4 of the 9), so no structural zeros are multiplied.  wp [Co][9*Ci].
+    res00 [B, ceil(Fo/2), ceil(To/2), Co] (compact): added to the even-even output pixels -- the data gradient of a
+    1x1 stride-2 conv over the same input (the ResNet downsample branch) lands exactly there."""
     Co, Ci = wp.shape[0], geom["cCi"]
     w4 = wp.view(Co, 3, 3, Ci)
     for pf in (0, 1):
@@ -99,6 +103,10 @@ def conv_gemm_transposed(x, wp, bias, out, geom):
                       b_ns=wq.shape[1], c_ms=Co, c_ns=1, dtype=_dt(x), a_mode=1, cphase=1 + 2 * pf + pt, **geom)
             if bias is not None:
                 kw.update(bias=bias, bias_mode=1)
+            if res00 is not None and pf == 0 and pt == 0:
+                if tuple(res00.shape) != (geom["cB"], Fp, Tp, Co) or not res00.is_contiguous():
+                    raise DttError("conv_gemm_transposed: res00 must be a contiguous [B, ceil(Fo/2), ceil(To/2), Co] tensor")
+                kw.update(R=res00, r_ms=Co, r_ns=1)
             gemm_raw(**kw)
 
 
@@ -209,6 +217,51 @@ def binary(op, a, b):
     out = torch.empty_like(a)
     check(lib().dtt_binary(op, ptr(a), ptr(b), ptr(out), C.c_int64(a.numel()), _dt(a), stream_ptr()), "dtt_binary")
     return out
+
+
+# --------------------------------------------------------------------------- #
+# Gradient hand-over between the two consumers of one tensor
+# --------------------------------------------------------------------------- #
+class GradSlot:
+    """A tensor with two consumers (the input of a TFC-TDF block: conv1[0] and skip_conv, block_tfc_tdf.py:40-41; an
+    encoder skip: the down-sampling conv and the decoder's multiply, encoder.py:43-46 / decoder.py:43; the input of a
+    ResNet block: conv1 and the residual / downsample branch, resnet.py:57-81) gets its gradient as the SUM of two
+    partial gradients, which the autograd engine forms with a separate add kernel per tensor (29 per cfg4 step,
+    848 MB written).  Both consumers are given one GradSlot: the one whose backward runs FIRST parks its partial
+    gradient here and reports None; the one that runs second -- always a convolution's data gradient -- takes it as the
+    residual input of its dgrad kernel (added in the epilogue, no extra pass) and reports the sum.  Which runs first is
+    fixed by data dependence in every pairing used here (the parking node is upstream in backward order), except
+    the ResNet downsample pairing, which handles both orders (Conv1x1s2.backward).
+    A slot serves ONE backward pass of ONE forward; an unconsumed slot just means the plain autograd add happened."""
+    __slots__ = ("g", "kind")
+
+    def __init__(self):
+        self.g, self.kind = None, None
+
+    def put(self, g, kind="full"):
+        self.g, self.kind = g, kind
+
+    def take(self):
+        g, k = self.g, self.kind
+        self.g, self.kind = None, None
+        return g, k
+
+
+_GRAD_SLOTS = os.environ.get("DTT_GRAD_SLOT", "1") != "0"      # 0: plain autograd accumulation (A/B switch)
+
+
+def new_slot(t):
+    """A GradSlot for tensor `t` and its two consumers, or None when t needs no gradient (or DTT_GRAD_SLOT=0)."""
+    return GradSlot() if (_GRAD_SLOTS and t.requires_grad and torch.is_grad_enabled()) else None
+
+
+def _slot_take(slot, want="full"):
+    if slot is None:
+        return None
+    g, k = slot.take()
+    if g is not None and k != want:
+        raise DttError(f"GradSlot holds a {k!r} partial gradient where {want!r} was expected")
+    return g
 
 
 # --------------------------------------------------------------------------- #
@@ -423,20 +476,24 @@ def _pack_dgrad(w, kind, dt):
     return _pp("pdup", w, (0, 2, 3, 1), dt).view(w.shape[0], -1)                    # up: [Ci][tap][Co]
 
 
-def _conv_backward(kind, x, w, dy, need_dx, tile=True, phases=False):
+def _conv_backward(kind, x, w, dy, need_dx, tile=True, phases=False, res=None, res00=None):
     """dy: gradient of the raw conv output [B,Fo,To,Co]. Returns dx, dw (param layout, fp32).  tile=False keeps a
-    stride-1 conv off the 16x16-pixel tile kernels (small images: Conv3x3)."""
+    stride-1 conv off the 16x16-pixel tile kernels (small images: Conv3x3).  res (shape of x) / res00 (compact,
+    even pixels: see conv_gemm_transposed): a partial input gradient from x's other consumer, added in the data
+    gradient's epilogue (GradSlot)."""
     B, Fi, Ti, Ci = x.shape
     Co = dy.shape[3]
     _, _, _, gd, gw = _conv_geoms(kind, B, Fi, Ti, Ci, Co)
     if kind == "s1" and tile and _fast3(dy, Ci) and _fast3(x, Co):
         if x.dtype == torch.bfloat16:
             need = lib().dtt_conv3x3_wgrad_ws_bytes(B, Fi, Ti, Ci, Co)
-            if need > 0:        # partial sums through a workspace + one sum launch instead of fp32 atomics
-                dwp = _empty((Co, 9, Ci), F32, x.device)
+            if need > 0:        # partial sums through a workspace + one sum launch instead of fp32 atomics;
+                dw = _empty((Co, Ci, 3, 3), F32, x.device)      # the sum writes the parameter's own layout
                 ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-                check(lib().dtt_conv3x3_wgrad_ws(ptr(dy), ptr(x), ptr(dwp), ptr(ws), C.c_int64(need), B, Fi, Ti, Ci, Co, 1,
-                                                 stream_ptr()), "dtt_conv3x3_wgrad_ws")
+                check(lib().dtt_conv3x3_wgrad_ws_param(ptr(dy), ptr(x), ptr(dw), ptr(ws), C.c_int64(need), B, Fi, Ti, Ci,
+                                                       Co, 1, stream_ptr()), "dtt_conv3x3_wgrad_ws_param")
+                dx = conv3x3_s1(dy, _pack_dgrad(w, kind, x.dtype), None, res=res)[0] if need_dx else None
+                return dx, dw
             else:
                 dwp = _zeros_f32((Co, 9, Ci,), x.device)
                 check(lib().dtt_conv3x3_wgrad(ptr(dy), ptr(x), ptr(dwp), B, Fi, Ti, Ci, Co, 1, stream_ptr()),
@@ -444,7 +501,7 @@ def _conv_backward(kind, x, w, dy, need_dx, tile=True, phases=False):
         else:
             dwp = conv_wgrad(dy, x, gw, Co, Ci)
         dw = dwp.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
-        dx = conv3x3_s1(dy, _pack_dgrad(w, kind, x.dtype), None)[0] if need_dx else None
+        dx = conv3x3_s1(dy, _pack_dgrad(w, kind, x.dtype), None, res=res)[0] if need_dx else None
         return dx, dw
     if kind == "up":
         dwp = conv_wgrad(x, dy, gw, Ci, Co)                      # [Ci][9][Co]
@@ -455,7 +512,7 @@ def _conv_backward(kind, x, w, dy, need_dx, tile=True, phases=False):
     dx = None
     if need_dx:
         dx = torch.empty_like(x)
-        conv_gemm(dy, _pack_dgrad(w, kind, x.dtype), None, dx, gd, phases=phases)
+        conv_gemm(dy, _pack_dgrad(w, kind, x.dtype), None, dx, gd, phases=phases, res=res, res00=res00)
     return dx, dw.contiguous()
 
 
@@ -464,10 +521,11 @@ class ConvNormGelu(torch.autograd.Function):
     Reference: block_tfc_tdf.py:12-17, block_sampling.py:8-12,23-28, decoder.py:46-52."""
 
     @staticmethod
-    def forward(ctx, x, w, b, kind, crop):
+    def forward(ctx, x, w, b, kind, crop, slot=None):
         B, Fi, Ti, Ci = x.shape
         Co = w.shape[1] if kind == "up" else w.shape[0]
         Fo, To, gf, _, _ = _conv_geoms(kind, B, Fi, Ti, Ci, Co)
+        ctx.slot = slot
         if kind == "s1" and _fast3(x, Co):
             y, stats = conv3x3_s1(x, _pack_fwd(w, kind, x.dtype), b, want_stats=True)
         else:
@@ -484,20 +542,22 @@ class ConvNormGelu(torch.autograd.Function):
     def backward(ctx, dz):
         x, w, y, stats = ctx.saved_tensors
         dy = in_gelu_bwd(y, dz.contiguous(), stats)
-        dx, dw = _conv_backward(ctx.kind, x, w, dy, ctx.needs_input_grad[0])
+        res = _slot_take(ctx.slot) if ctx.needs_input_grad[0] else None     # x's other consumer ran first (GradSlot)
+        dx, dw = _conv_backward(ctx.kind, x, w, dy, ctx.needs_input_grad[0], res=res)
         # the bias feeds an affine-free InstanceNorm: its gradient is identically zero
         db = _zeros_f32((w.shape[1] if ctx.kind == "up" else w.shape[0],), x.device)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class ConvAdd(torch.autograd.Function):
     """skip_conv(x) + h  (block_tfc_tdf.py:41,46): conv3x3 with bias and a fused residual add."""
 
     @staticmethod
-    def forward(ctx, x, w, b, h):
+    def forward(ctx, x, w, b, h, slot=None):
         B, Fi, Ti, Ci = x.shape
         Co = w.shape[0]
         _, _, gf, _, _ = _conv_geoms("s1", B, Fi, Ti, Ci, Co)
+        ctx.slot = slot
         if _fast3(x, Co):
             y = conv3x3_s1(x, _pack_fwd(w, "s1", x.dtype), b, res=h)[0]
         else:
@@ -513,7 +573,10 @@ class ConvAdd(torch.autograd.Function):
         dx, dw = _conv_backward("s1", x, w, dy, ctx.needs_input_grad[0])
         Co = dy.shape[3]
         db = colsum(dy, dy.numel() // Co, Co)
-        return dx, dw, db, dy
+        if ctx.slot is not None and dx is not None:
+            ctx.slot.put(dx)                 # x's other consumer (conv1[0]) adds it inside its data-gradient conv
+            dx = None
+        return dx, dw, db, dy, None
 
 
 class Conv3x3(torch.autograd.Function):
@@ -526,7 +589,8 @@ class Conv3x3(torch.autograd.Function):
     (ours: 324-365 vs 285-306 us)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride=1):
+    def forward(ctx, x, w, stride=1, slot=None):
+        ctx.slot = slot
         xc = x.permute(0, 2, 3, 1)
         if not xc.is_contiguous():
             xc = xc.contiguous()
@@ -551,8 +615,27 @@ class Conv3x3(torch.autograd.Function):
         dyc = dy.permute(0, 2, 3, 1)
         if not dyc.is_contiguous():
             dyc = dyc.contiguous()
-        dx, dw = _conv_backward(ctx.kind, xc, w, dyc, ctx.needs_input_grad[0], tile=ctx.tile, phases=True)
-        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dw, None
+        res = res00 = None
+        if ctx.slot is not None and ctx.needs_input_grad[0]:
+            g, k = ctx.slot.take()           # the partial gradient of x's other consumer, if it ran first (GradSlot)
+            if k == "even":                  # Conv1x1s2 (downsample branch): compact, lands on the even pixels
+                res00 = g
+            elif g is not None:              # BatchNormAct's residual input: shape of x (NCHW view, channels-last)
+                res = g.permute(0, 2, 3, 1)
+                if not res.is_contiguous():
+                    res = res.contiguous()
+        if res00 is not None and ctx.kind != "down":
+            raise DttError("Conv3x3: an even-pixel partial gradient needs the stride-2 form")
+        dx, dw = _conv_backward(ctx.kind, xc, w, dyc, ctx.needs_input_grad[0], tile=ctx.tile, phases=True, res=res,
+                                res00=res00)
+        if dx is not None:
+            dx = dx.permute(0, 3, 1, 2)
+            if ctx.slot is not None and res is None and res00 is None and ctx.kind == "down":
+                # ran BEFORE the downsample branch's backward (engine order): park the full gradient, Conv1x1s2
+                # adds its own part to the even pixels
+                ctx.slot.put(dx, "full")
+                dx = None
+        return dx, dw, None, None
 
 
 class Conv1x1s2(torch.autograd.Function):
@@ -562,7 +645,8 @@ class Conv1x1s2(torch.autograd.Function):
     no padding); the data gradient is a plain GEMM scattered to the even pixels of a zeroed tensor."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, slot=None):
+        ctx.slot = slot
         xc = x.permute(0, 2, 3, 1)
         if not xc.is_contiguous():
             xc = xc.contiguous()
@@ -596,10 +680,23 @@ class Conv1x1s2(torch.autograd.Function):
             t = _empty((P, Ci), xc.dtype, xc.device)
             wq = w.view(Co, Ci).to(xc.dtype)                         # [Co][Ci]: B(k = co, n = ci) row-contiguous
             gemm_raw(A=dyc, B=wq, C=t, M=P, N=Ci, K=Co, a_ms=Co, a_ks=1, b_ks=Ci, b_ns=1, c_ms=Ci, c_ns=1, dtype=_dt(xc))
-            dx = torch.zeros_like(xc)
-            dx[:, ::2, ::2] = t.view(B, g["cFo"], g["cTo"], Ci)
-            dx = dx.permute(0, 3, 1, 2)
-        return dx, dwp.view(Co, Ci, 1, 1)
+            t = t.view(B, g["cFo"], g["cTo"], Ci)
+            full, kind = ctx.slot.take() if ctx.slot is not None else (None, None)
+            if full is not None:
+                # the 3x3 stride-2 conv over the same x already ran: add this branch to its even pixels, report the sum
+                dxc = full.permute(0, 2, 3, 1)
+                dxc[:, ::2, ::2] += t
+                dx = full
+            elif ctx.slot is not None:
+                # normal order: the 3x3 stride-2 conv's four-parity data gradient takes t as the residual of its
+                # even-even GEMM (no 180 MB zero fill + strided scatter + add per block)
+                ctx.slot.put(t, "even")
+                dx = None
+            else:
+                dx = torch.zeros_like(xc)
+                dx[:, ::2, ::2] = t
+                dx = dx.permute(0, 3, 1, 2)
+        return dx, dwp.view(Co, Ci, 1, 1), None
 
 
 class FrontConv(torch.autograd.Function):
@@ -1074,15 +1171,20 @@ class MulSkip(torch.autograd.Function):
     """out = a * skip  (decoder.py:43)."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, slot=None):
         ctx.save_for_backward(a, b)
+        ctx.slot = slot
         return binary(1, a, b)
 
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         g = g.contiguous()
-        return binary(1, g, b), binary(1, g, a)
+        ga, gb = binary(1, g, b), binary(1, g, a)
+        if ctx.slot is not None and ctx.needs_input_grad[1]:
+            ctx.slot.put(gb)                 # the skip's other consumer (the encoder's down-sampling conv) adds it
+            gb = None
+        return ga, gb, None
 
 
 class InitConv(torch.autograd.Function):
@@ -1419,21 +1521,31 @@ class Film(torch.autograd.Function):
 
 class FreqMeanTokens(torch.autograd.Function):
     """tokens[b,t,c] = mean_f x[b,f,t,c] (cross_attention_positional.py:55) -> fp32.
-    Its backward is folded into BroadcastConcat (the only consumer of x besides this)."""
+    With a GradSlot shared with BroadcastConcat (x's other consumer, whose backward runs first: the token network
+    hangs off its enh gradient) the two partial gradients of x are formed by ONE pass, here: dx = dout[..., :C] +
+    dtok / F.  Without a slot: the plain broadcast, summed by autograd."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, slot=None):
         B, Fq, T, Cc = x.shape
         tok = _empty((B, T, Cc), F32, x.device)
         check(lib().dtt_fmean(ptr(x), ptr(tok), B, Fq, T, Cc, _dt(x), stream_ptr()), "dtt_fmean")
         ctx.shape = x.shape
         ctx.dt = x.dtype
+        ctx.slot = slot
         return tok
 
     @staticmethod
     def backward(ctx, dtok):
         B, Fq, T, Cc = ctx.shape
-        return (dtok / Fq).to(ctx.dt).unsqueeze(1).expand(B, Fq, T, Cc).contiguous()
+        dout = _slot_take(ctx.slot, "bcat")
+        if dout is not None:
+            dtok = dtok.contiguous().float()
+            dx = _empty((B, Fq, T, Cc), dout.dtype, dout.device)
+            check(lib().dtt_bcat_bwd(ptr(dout), ptr(dtok), ptr(dx), None, B, Fq, T, Cc, _dt(dout), stream_ptr()),
+                  "dtt_bcat_bwd")
+            return dx, None
+        return (dtok / Fq).to(ctx.dt).unsqueeze(1).expand(B, Fq, T, Cc).contiguous(), None
 
 
 class BroadcastConcat(torch.autograd.Function):
@@ -1441,11 +1553,12 @@ class BroadcastConcat(torch.autograd.Function):
     temporal_alignment.py:17-24)."""
 
     @staticmethod
-    def forward(ctx, x, enh):
+    def forward(ctx, x, enh, slot=None):
         B, Fq, T, Cc = x.shape
         enh = enh.contiguous().float()
         out = _empty((B, Fq, T, 2 * Cc), x.dtype, x.device)
         check(lib().dtt_bcat_fwd(ptr(x), ptr(enh), ptr(out), B, Fq, T, Cc, _dt(x), stream_ptr()), "dtt_bcat_fwd")
+        ctx.slot = slot
         return out
 
     @staticmethod
@@ -1453,11 +1566,17 @@ class BroadcastConcat(torch.autograd.Function):
         B, Fq, T, C2 = dout.shape
         Cc = C2 // 2
         dout = dout.contiguous()
-        dx = _empty((B, Fq, T, Cc), dout.dtype, dout.device)
         denh = _empty((B, T, Cc), F32, dout.device)
+        if ctx.slot is not None and ctx.needs_input_grad[0]:
+            # x's half waits for the token mean's gradient (FreqMeanTokens.backward forms dx in one pass)
+            check(lib().dtt_bcat_bwd(ptr(dout), None, None, ptr(denh), B, Fq, T, Cc, _dt(dout), stream_ptr()),
+                  "dtt_bcat_bwd")
+            ctx.slot.put(dout, "bcat")
+            return None, denh, None
+        dx = _empty((B, Fq, T, Cc), dout.dtype, dout.device)
         check(lib().dtt_bcat_bwd(ptr(dout), None, ptr(dx), ptr(denh), B, Fq, T, Cc, _dt(dout), stream_ptr()),
               "dtt_bcat_bwd")
-        return dx, denh
+        return dx, denh, None
 
 
 # --------------------------------------------------------------------------- #
@@ -1470,7 +1589,8 @@ class BatchNormAct(torch.autograd.Function):
     eval mode; nothing but x (and res) is saved: backward recomputes the activation input."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, rmean, rvar, training, momentum, eps, act):
+    def forward(ctx, x, res, gamma, beta, rmean, rvar, training, momentum, eps, act, slot=None):
+        ctx.slot = slot
         if x.dim() != 4:
             raise DttError("BatchNormAct expects an NCHW tensor")
         x = x.contiguous(memory_format=torch.channels_last)
@@ -1515,7 +1635,10 @@ class BatchNormAct(torch.autograd.Function):
         check(lib().dtt_bn_act_bwd(ptr(x), ptr(res), ptr(dz), ptr(stats), ptr(gamma), ptr(beta), ptr(part), ptr(sums),
                                    ptr(dgb), ptr(dx), ptr(dres), P, Cc, act, 1 if training else 0, d, stream_ptr()),
               "dtt_bn_act_bwd")
-        return dx, dres, dgb[:, 0].contiguous(), dgb[:, 1].contiguous(), None, None, None, None, None, None
+        if ctx.slot is not None and dres is not None:
+            ctx.slot.put(dres)               # the residual's other consumer (the block's conv1) adds it in its dgrad
+            dres = None
+        return dx, dres, dgb[:, 0].contiguous(), dgb[:, 1].contiguous(), None, None, None, None, None, None, None
 
 
 def _bn_momentum(bn):
@@ -1530,13 +1653,14 @@ def _bn_momentum(bn):
     return float(bn.momentum)
 
 
-def batch_norm_act(x, bn, act, res=None):
-    """``bn``: an nn.BatchNorm2d (parameter / buffer container; its train()/eval() mode is honoured)."""
+def batch_norm_act(x, bn, act, res=None, slot=None):
+    """``bn``: an nn.BatchNorm2d (parameter / buffer container; its train()/eval() mode is honoured).  slot: GradSlot
+    shared with the residual's other consumer."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     mom = _bn_momentum(bn)
     use_batch = bn.training or not bn.track_running_stats
-    return BatchNormAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, act)
+    return BatchNormAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, act, slot)
 
 
 _POOL_BWD_FUSED = os.environ.get("DTT_POOL_BWD_FUSED", "0") == "1"

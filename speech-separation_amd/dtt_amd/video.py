@@ -28,9 +28,9 @@ _FUSED_POOL = os.environ.get("DTT_VIDEO_FUSED_POOL", "1") == "1"   # 0: front-en
 _OWN_S2 = os.environ.get("DTT_VIDEO_S2_CONV", "1") == "1"         # 0: the trunk's stride-2 3x3 and 1x1 convolutions on MIOpen
 
 
-def _conv3x3(conv, x):
+def _conv3x3(conv, x, slot=None):
     """The trunk's convolutions on the HIP kernels: 3x3 stride 1 / 2 (ops.Conv3x3) and the 1x1 stride-2 downsample
-    (ops.Conv1x1s2); anything else on MIOpen."""
+    (ops.Conv1x1s2); anything else on MIOpen.  slot: ops.GradSlot shared with x's other consumer in the block."""
     ok = (_OWN_CONV and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.bias is None
           and x.dtype in (torch.bfloat16, torch.float32))
     k, st, pd = conv.kernel_size, conv.stride, conv.padding
@@ -40,9 +40,18 @@ def _conv3x3(conv, x):
         if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_dtype("cuda"))
         if k == (1, 1):
-            return Conv1x1s2.apply(x, conv.weight)
-        return Conv3x3.apply(x, conv.weight, st[0])
+            return Conv1x1s2.apply(x, conv.weight, slot)
+        return Conv3x3.apply(x, conv.weight, st[0], slot)
     return conv(x)
+
+
+def _slot_ok(conv, x):
+    """True when _conv3x3 will run this convolution on the HIP kernels (only those take part in a GradSlot)."""
+    k, st, pd = conv.kernel_size, conv.stride, conv.padding
+    return (_OWN_CONV and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and conv.bias is None
+            and x.dtype in (torch.bfloat16, torch.float32)
+            and ((k == (3, 3) and pd == (1, 1) and (st == (1, 1) or (st == (2, 2) and _OWN_S2)))
+                 or (k == (1, 1) and pd == (0, 0) and st == (2, 2) and _OWN_S2)))
 
 
 class _NativeBN:
@@ -91,10 +100,20 @@ class BasicBlock(nn.Module):
             return self.relu2(y + r)
         # BatchNorm + Swish (+ residual) as ONE HIP pass forward and two backward (ops.BatchNormAct); the stride-1
         # 3x3 convolutions on our kernels, the stride-2 / 1x1 ones on MIOpen
-        from .ops import batch_norm_act
-        r = x if self.downsample is None else batch_norm_act(_conv3x3(self.downsample[0], x), self.downsample[1], 0)
-        y = batch_norm_act(_conv3x3(self.conv1, x), self.bn1, 1)
-        return batch_norm_act(_conv3x3(self.conv2, y), self.bn2, 1, res=r)
+        # x has two consumers (conv1 and the residual / downsample branch): their partial gradients meet inside
+        # conv1's data-gradient kernel instead of an autograd add (ops.GradSlot).  conv1 is issued FIRST so that the
+        # engine, which runs ready nodes in reverse order of creation, reaches the downsample conv's backward before
+        # conv1's (either order is handled).
+        from .ops import batch_norm_act, new_slot
+        own = _slot_ok(self.conv1, x) and (self.downsample is None or _slot_ok(self.downsample[0], x))
+        slot = new_slot(x) if own else None
+        y = _conv3x3(self.conv1, x, slot)
+        if self.downsample is None:
+            r, rslot = x, slot
+        else:
+            r, rslot = batch_norm_act(_conv3x3(self.downsample[0], x, slot), self.downsample[1], 0), None
+        y = batch_norm_act(y, self.bn1, 1)
+        return batch_norm_act(_conv3x3(self.conv2, y), self.bn2, 1, res=r, slot=rslot)
 
 
 class ResNet18Trunk(nn.Module):

@@ -185,7 +185,8 @@ def build_workload(name, args, dev, rank, world, reducer_cls):
             torch.cuda.synchronize()
             opt = dtt_amd.ClipAdamW([{"params": decay, "weight_decay": 1e-5},
                                      {"params": no_decay, "weight_decay": 0.0}], lr=1e-4, max_norm=2.0)
-    return dict(cfg=cfg, B=B, L=L, n_fft=n_fft, hop=hop, step=step, opt=opt, mode=mode, model=model)
+    return dict(cfg=cfg, B=B, L=L, n_fft=n_fft, hop=hop, step=step, opt=opt, mode=mode, model=model,
+                eager_step=eager_step, reducer=reducer)
 
 
 def time_workload(w, steps, warmup, world, dev, backend):
@@ -286,8 +287,9 @@ def main():
     opt_ms = e0.elapsed_time(e1) / 5
 
     roofline = cpu = also = None
-    if rank == 0 and not args.no_roofline:
-        roofline = dominant_kernel_roofline(cfg, B, args.precision, dev)
+    if not args.no_roofline:
+        # every rank issues the eager steps (with N > 1 they hold the gradient all-reduce); rank 0 reports
+        roofline = step_roofline(w, cfg, B, args.precision, args.workload)
     if rank == 0 and world == 1 and not args.no_also and args.workload != "audio15m" and args.batch is None:
         # BASELINE.json configs[1] (the round-1 headline), measured the same way in the same process
         del w
@@ -331,140 +333,77 @@ def main():
         dist.destroy_process_group()
 
 
-def _events_time(launch, n=20, warm=3):
-    for _ in range(warm):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()                      # torch's current stream == the stream the C ABI launches on (stream_ptr())
-    for _ in range(n):
-        launch()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n / 1e3
-
-
-def _time_conv(ops, B, Fq, T, Cc, dt, dev, n=20):
-    x = torch.randn(B, Fq, T, Cc, device=dev).to(dt)
-    w = (torch.randn(Cc, Cc, 3, 3, device=dev) / (3.0 * Cc ** 0.5))
-    bias = torch.zeros(Cc, device=dev)
-    wp = ops._pack_fwd(w, "s1", dt)
-    import ctypes as C
-    from dtt_amd._lib import lib, check, ptr, stream_ptr, dtype_code
-    y = torch.empty_like(x)
-    part = torch.empty(B * (4 * ((Fq + 15) // 16) * ((T + 15) // 16) + 4) * Cc * 3, dtype=torch.float32, device=dev)
-
-    def launch():                    # stats = NULL: the kernel with its fused statistics, without the merge launch
-        check(lib().dtt_conv3x3_s1(ptr(x), ptr(wp), ptr(bias), ptr(y), None, ptr(part), None, B, Fq, T, Cc, Cc,
-                                   C.c_float(1e-5), dtype_code(dt), stream_ptr()), "dtt_conv3x3_s1")
-    return _events_time(launch, n)
-
-
-def _time_lstm(ops, B, g, seconds, dt, dev):
-    """The time-axis recurrent forward pass of one TC_FC_RNN at the workload's latent size, through the C ABI:
-    N = B * heads * 65 sequences of L = T/8 steps, C' = 8g (x-attn latent: 16g channels over 2 heads), H = 2C'.
-    The register-stationary kernel (lstm_rs.hip) at H = 512, the LDS-stationary cluster kernel (lstm_cluster.hip)
-    at the other widths it covers, else the streaming kernel."""
-    import ctypes as C
-    from dtt_amd._lib import lib, check, ptr, stream_ptr, dtype_code
-    heads, Fq = 2, 65
-    Cp, L = 8 * g, (1 + int(seconds * SR) // 256 + 7) // 8
-    H, N = 2 * Cp, B * heads * Fq
-    R = N * L
-    d = dtype_code(dt)
-    xg = (torch.randn(R, 8 * H, device=dev) * 0.5).to(dt)
-    whh = torch.randn(2, 4 * H, H, device=dev) / H ** 0.5
-    y = torch.empty(R, 2 * H, device=dev, dtype=dt)
-    rs = ops._rs_ok(N, L, H, d, heads, "auto")
-    geom = None if rs else ops._cluster_geometry(N, H, d)
-    if rs:
-        NT = (N + 31) // 32
-        wt = whh.to(dt).contiguous()
-        gates = torch.empty(2, NT, L, 4 * H * 32, device=dev, dtype=dt)
-        cst = torch.empty(2, NT, L, H * 32, device=dev, dtype=torch.float32)
-        sync = torch.empty(lib().dtt_lstm_rs_sync_words(N, H), device=dev, dtype=torch.int32)
-        name = ("lstm_rs_fwd_deep_kernel (dtt_lstm_rs_fwd: BiLSTM recurrence, W_hh resident in the AGPRs of 8-CU "
-                "clusters, h tile once per CU through LDS")
-
-        def launch():
-            check(lib().dtt_lstm_rs_fwd(ptr(xg), ptr(wt), ptr(y), ptr(gates), ptr(cst), ptr(sync), N, L, heads, H, d,
-                                        stream_ptr()), "dtt_lstm_rs_fwd")
-    elif geom is not None:
-        NT = (N + 31) // 32
-        wt = whh.to(dt).contiguous()
-        gates = torch.empty(2, NT, L, 4 * H * 32, device=dev, dtype=dt)
-        cst = torch.empty(2, NT, L, H * 32, device=dev, dtype=torch.float32)
-        sync = torch.empty(lib().dtt_lstm_cluster_sync_words(geom[2]), device=dev, dtype=torch.int32)
-        name = (f"lstm_cluster_fwd_kernel (dtt_lstm_cluster_fwd: BiLSTM recurrence, W_hh resident in LDS over "
-                f"{geom[1]} CUs per group, {2 * geom[2]} groups")
-
-        def launch():
-            check(lib().dtt_lstm_cluster_fwd(ptr(xg), ptr(wt), ptr(y), ptr(gates), ptr(cst), ptr(sync), N, L, heads, H, d,
-                                             stream_ptr()), "dtt_lstm_cluster_fwd")
-    else:
-        wp = torch.stack([ops._pack_whh_fwd(whh[0], dt), ops._pack_whh_fwd(whh[1], dt)]).contiguous()
-        gates = torch.empty(R, 2, 4 * H, device=dev, dtype=dt)
-        cst = torch.empty(R, 2, H, device=dev, dtype=torch.float32)
-        name = "lstm_fwd_kernel (dtt_lstm_fwd: BiLSTM recurrence, W_hh streamed from L2 every step"
-
-        def launch():
-            check(lib().dtt_lstm_fwd(ptr(xg), ptr(wp), ptr(y), ptr(gates), ptr(cst), N, L, heads, H, d, stream_ptr()),
-                  "dtt_lstm_fwd")
-    sec = _events_time(launch, n=10)
-    flops = 2.0 * N * L * 2 * H * 4 * H                    # h_{t-1} W_hh^T, both directions
-    return {"kernel": f"{name}; N={N} sequences x L={L} steps, H={H}; 4 launches of this shape + 4 of the "
-                      f"frequency-axis shape forward, as many backward, per step)",
-            "achieved": round(flops / sec / 1e12, 2), "avg_launch_us": round(sec * 1e6, 1), "flops_per_launch": flops,
-            "traffic_key": f"lstm_fwd_H{H}_N{N}_L{L}"}
-
-
 def _tracked_traffic(key):
-    """HBM bytes per launch from the tracked rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, written by
+    """HBM bytes per launch from the tracked rocprofv3 --pmc passes (profiles/r0*_pmc_traffic.json, written by
     tools/pmc_kernels.py from separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled for gfx950).  None when
-    no such measurement is tracked for this kernel and shape."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+    no such measurement is tracked for this entry point and shape."""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                v = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+            if v is not None:
+                return v
+        except (OSError, ValueError):
+            pass
+    return None
 
 
-def dominant_kernel_roofline(cfg, B, precision, dev):
-    """Roofline of the kernel with the largest share of the step (rocprofv3, profiles/), timed here alone through
-    the C ABI with events on the launch stream.
+def _traffic_key(row):
+    sh = row["shape"]
+    if row["entry"] == "dtt_lstm_rs_fwd":
+        return f"lstm_fwd_H{sh['H']}_N{sh['N']}_L{sh['L']}"
+    if row["entry"] == "dtt_conv3x3_s1" and sh.get("Ci") == 64 and sh.get("F") == 257:
+        return f"conv3x3_s1_B{sh['B']}"
+    if row["entry"] == "dtt_conv3x3_s1" and sh.get("Ci") == 32:
+        return f"conv3x3_c32_B{sh['B']}"
+    return "%s_%s" % (row["entry"], "_".join(f"{k}{v}" for k, v in sorted(sh.items()) if k not in ("form", "dtype")))
 
-    AV cross-attention (cfg4 / cfg5): the recurrent kernel of the dual-path LSTMs (H = 2C' = 512 / 1024), MFMA
-    bound: 2 * N * L * 2 directions * H * 4H flop per launch for the recurrence (+ the input projection where the
-    kernel fuses it).  Audio-only / FiLM (cfg2 / cfg3): the 3x3 conv of U-Net levels 1-3, conv3x3_s1_kernel."""
-    from dtt_amd import ops
-    dt = torch.bfloat16 if precision == "bf16" else torch.float32
-    es = 2 if precision == "bf16" else 4
-    out = None
-    if cfg["model"] == "xattn":
-        out = _time_lstm(ops, B, cfg["g"], cfg["seconds"], dt, dev)
-        out["peak"], out["unit"], out["bound"] = PEAK_BF16_TFLOPS, "TFLOP/s", "mfma"
-        out["frac"] = round(out["achieved"] / PEAK_BF16_TFLOPS, 4)
-        out["traffic"] = _tracked_traffic(out.pop("traffic_key")) if B == cfg["batch"] and precision == "bf16" else None
-    Fq, T, Cc = 257, 63, 64
-    sec = _time_conv(ops, B, Fq, T, Cc, dt, dev)
-    flops = 2.0 * B * Fq * T * Cc * 9 * Cc
-    achieved = flops / sec / 1e12
-    conv = {"kernel": f"conv3x3_s1_kernel<bf16,{1 if 17 * 4 * B <= 1152 else 2}> (conv3x3 64->64 @ [B,257,63] + fused InstanceNorm statistics)",
-            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": _tracked_traffic(f"conv3x3_s1_B{B}") if precision == "bf16" else None,
-            "avg_launch_us": round(sec * 1e6, 1), "flops_per_launch": flops}
-    sec0 = _time_conv(ops, B, 513, 126, 32, dt, dev)
-    bytes0 = 2.0 * B * 513 * 126 * 32 * es                # read x + write y once
-    c32 = {"kernel": "conv3x3_c32_kernel (conv3x3 32->32 @ [B,513,126])", "bound": "hbm",
-           "achieved": round(bytes0 / sec0 / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-           "frac": round(bytes0 / sec0 / (PEAK_HBM_GBS * 1e9), 4), "avg_launch_us": round(sec0 * 1e6, 1),
-           "traffic": _tracked_traffic(f"conv3x3_c32_B{B}") if precision == "bf16" else None,
-           "bytes_per_launch": bytes0}
-    if out is None:
-        conv["also"] = [c32]
-        return conv
-    out["also"] = [conv, c32]
-    return out
+
+def step_roofline(w, cfg, B, precision, workload):
+    """Roofline that FOLLOWS THE TIME: three eagerly issued steps of the workload just timed, every libdtt_hip call
+    bracketed by HIP events on the launch stream (dtt_amd.prof.CallTimer), grouped by (entry point, shape).  The
+    headline entry is the one with the largest share of the step; `top` lists the five largest with their shapes,
+    launches per step, average duration, algorithmic flops or bytes per launch and fraction of the
+    roofline that bounds them; `by_family` sums the step by kernel family.  The same table, all rows, is written by
+    tools/step_table.py and tracked under profiles/."""
+    from dtt_amd import prof
+    step = w["eager_step"]
+    for i in range(2):
+        step(i)
+    torch.cuda.synchronize()
+    n = 3
+    with prof.CallTimer() as ct:
+        for i in range(n):
+            step(i)
+    tab = ct.table(n)
+    rows = tab["rows"]
+    for r in rows:
+        r["share_of_step"] = round(r["ms_per_step"] / tab["span_ms_per_step"], 4)
+    priced = [r for r in rows if "frac" in r]
+    top = priced[:5]
+    fam = {}
+    for r in rows:
+        e = r["entry"]
+        k = ("lstm recurrence" if "lstm" in e else "3x3 conv (tile kernels)" if e == "dtt_conv3x3_s1" else
+             "3x3 conv weight gradient (tile kernels)" if "wgrad" in e else "gemm (Linear / implicit-GEMM conv / DFT)" if e == "dtt_gemm"
+             else "InstanceNorm + GELU" if "in_gelu" in e or e == "dtt_in_stats" else "BatchNorm / pool (lip encoder)" if "bn_" in e or "pool" in e
+             else "other entry points")
+        fam[k] = round(fam.get(k, 0.0) + r["ms_per_step"], 3)
+    fam["outside entry points (torch glue, launch gaps of the eager issue)"] = tab["outside_entry_points_ms_per_step"]
+    head = dict(top[0]) if top else {}
+    if head:
+        sh = " ".join(f"{k}={v}" for k, v in head["shape"].items())
+        head["kernel"] = f"{head['entry']} [{sh}]: {head['launches_per_step']:g} launches per step, {head['share_of_step'] * 100:.1f} % of the eagerly issued step"
+        head["avg_launch_us"] = head["avg_us"]
+        head["traffic"] = _tracked_traffic(_traffic_key(head)) if precision == "bf16" and B == cfg["batch"] else None
+    for r in top:
+        r["traffic"] = _tracked_traffic(_traffic_key(r)) if precision == "bf16" and B == cfg["batch"] else None
+    head["measured"] = (f"{n} eager steps of {workload} with HIP events around every C-ABI call on the launch stream "
+                        f"(dtt_amd/prof.py); eager step {tab['span_ms_per_step']:.2f} ms, of which {tab['entry_points_ms_per_step']:.2f} ms "
+                        f"inside entry points")
+    head["top"] = top
+    head["by_family_ms_per_step"] = fam
+    return head
 
 
 if __name__ == "__main__":

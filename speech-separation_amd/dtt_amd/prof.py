@@ -77,8 +77,10 @@ def _lstm(i0, fused=False):
             Cp = _v(args[i0 + 4])
             flops += 2.0 * N * L * 2 * Cp * 4 * H
             d["Cp"] = Cp
-        # xg / gates / cell states / y: 8H + 8H + 4H(fp32 = 2x) + 2H bf16 elements per row
-        return d, flops, N * L * (8 * H * 2 + 8 * H * 2 + 2 * H * 4 + 2 * H * 2)
+        # (bytes 0: priced against the MFMA peak like the contraction it replaces -- SURVEY 8(d) "LSTM input +
+        # recurrent GEMMs" -- although its saved activations, 8H + 8H + 2H bf16 and 2H fp32 per row, put its
+        # intensity just below the ridge)
+        return d, flops, 0.0
     return f
 
 

@@ -133,14 +133,23 @@ def build_workload(name, args, dev, rank, world, reducer_cls):
     if cfg["model"] in ("xattn", "film"):
         video = (torch.rand(B, 2, Tv, 88, 88, generator=gv, device=dev) - 0.421) / 0.165
     criterion = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())
-    reducer = reducer_cls(model)
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     decay = [p for n, p in named if "bias" not in n]
     no_decay = [p for n, p in named if "bias" in n]
     use_graph = args.graph != "0"
-    # clip_grad_norm_(2.0) + AdamW (train.yaml:20-23,59) in two launches
-    opt = dtt_amd.ClipAdamW([{"params": decay, "weight_decay": 1e-5}, {"params": no_decay, "weight_decay": 0.0}],
-                            lr=1e-4, max_norm=2.0, capturable=use_graph and world == 1)
+    sharded = bool(getattr(args, "sharded_optimizer", False)) and world > 1
+    if sharded:
+        # reduce-scatter -> clip + AdamW on this rank's 1/W of the parameters -> all-gather; the
+        # gradients are exchanged by the optimizer, not by a bucket reducer
+        from dtt_amd.dist import ShardedClipAdamW, LocalGrads
+        reducer = LocalGrads(model)
+        opt = ShardedClipAdamW(model, lr=1e-4, weight_decay=1e-5, weight_decay_of=lambda n: 0.0 if "bias" in n else 1e-5,
+                               max_norm=2.0)
+    else:
+        reducer = reducer_cls(model)
+        # clip_grad_norm_(2.0) + AdamW (train.yaml:20-23,59) in two launches
+        opt = dtt_amd.ClipAdamW([{"params": decay, "weight_decay": 1e-5}, {"params": no_decay, "weight_decay": 0.0}],
+                                lr=1e-4, max_norm=2.0, capturable=use_graph)
     pool = []
     for i in range(2):
         s1, s2 = synth_batch(B, L, 1234 + 1000 * rank + i, dev)
@@ -173,7 +182,10 @@ def build_workload(name, args, dev, rank, world, reducer_cls):
     if use_graph:
         try:
             gs = dtt_amd.GraphedTrainStep(model, criterion, opt, pool[0], batch_fn, reducer=reducer, warmup=2)
-            mode = "hip-graph" if world == 1 else "hip-graph(fwd+bwd) + eager all-reduce/optimizer"
+            mode = ("hip-graph(fwd+bwd) + sharded optimizer step (reduce-scatter / clip+AdamW on the shard / all-gather)"
+                    if sharded else "hip-graph" if world == 1 else
+                    "hip-graph (fwd + bwd + bucketed RCCL all-reduce overlapped with backward + optimizer, one launch)"
+                    if gs.overlap else "hip-graph(fwd+bwd) + eager all-reduce/optimizer")
 
             def step(i, gs=gs):
                 return gs(pool[i % len(pool)])
@@ -237,6 +249,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", default="auto", choices=["auto", "0", "1"],
                     help="record the step into a HIP graph and replay it (auto: fall back to eager if capture fails)")
+    ap.add_argument("--sharded-optimizer", action="store_true",
+                    help="N > 1: reduce-scatter -> clip + AdamW on 1/N of the parameters -> all-gather (ShardedClipAdamW) "
+                         "instead of bucketed all-reduce + replicated update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary audio15m (configs[1]) measurement")

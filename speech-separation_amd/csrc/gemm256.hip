@@ -400,7 +400,10 @@ int dtt_gemm256_try(const DttGemm& p, hipStream_t st) {
     const bool kc = p.a_ks == 1 && p.b_ks == 1 && p.b_mode == 0;
     const bool rc = p.a_ms == 1 && p.b_ns == 1 && (p.b_mode == 0 || p.b_mode == 2);
     if (kc) {
-        // plain store, k-contiguous operands
+        // plain store, k-contiguous operands (DTT_GEMM256_KC=0: leave them to gemmx.hip, which has this tile too)
+        static int kc_on = -1;
+        if (kc_on < 0) { const char* e = getenv("DTT_GEMM256_KC"); kc_on = e ? atoi(e) : 1; }
+        if (!kc_on) return 1;
         if (p.splitk != 1 || p.atomic || p.a_ms % 8 || p.b_ns % 8 || p.N % 8 || p.c_ms % 8 || p.bias_mode > 1 ||
             (p.R && (p.r_ns != 1 || p.r_ms % 8 || !al(p.R))) || tiles < 128)
             return 1;                                      // under half a tile per CU: the 128 x 128 form fills the chip better

@@ -13,4 +13,4 @@ from .io import (load_reference_checkpoint, save_reference_checkpoint, align_sta
                  write_wav_float32, save_separated)
 from .feeder import collate_on_device, spec_augment_on_device  # noqa: F401
 from .graph import GraphedTrainStep  # noqa: F401
-from .dist import GradBucketReducer, ShardedClipAdamW  # noqa: F401
+from .dist import GradBucketReducer, ShardedClipAdamW, LocalGrads  # noqa: F401

@@ -89,6 +89,17 @@ class GradBucketReducer:
         self._launched = [False] * len(self.buckets)
         self._next = 0                                    # buckets are exchanged strictly in index order
 
+    def capturable_collectives(self):
+        """True when the bucket all-reduces can be recorded into a HIP graph: RCCL ("nccl") on GPU buckets.  gloo's
+        collectives run on the host and the host-staged rehearsal path synchronises: neither can be recorded."""
+        return (self.world > 1 and not self._host_staged and bool(self.params) and self.params[0].is_cuda
+                and dist.get_backend(self.group) == "nccl")
+
+    def abort_step(self):
+        """Forget a half-issued exchange (a graph capture that failed between hooks and finish())."""
+        self._pending = []
+        self._reset()
+
     def pause_hooks(self, paused):
         """While a HIP graph of forward + backward is being recorded the hooks must not fire (a collective is
         not part of the recorded step); reduce_grads() exchanges the gradients behind each replay instead."""
@@ -190,6 +201,39 @@ class GradBucketReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+
+
+class LocalGrads:
+    """Stand-in for GradBucketReducer where the OPTIMIZER exchanges the gradients (ShardedClipAdamW: reduce-scatter
+    -> update of the shard -> all-gather): backward leaves local gradients in ``p.grad`` and nothing is all-reduced.
+    Same surface as the reducer for the training loop and for GraphedTrainStep (which then records forward +
+    backward and runs the sharded step behind each replay)."""
+
+    def __init__(self, module, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.buckets = []
+
+    def capturable_collectives(self):
+        return False
+
+    def pause_hooks(self, paused):
+        pass
+
+    def abort_step(self):
+        pass
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def finish(self):
+        pass
+
+    def reduce_grads(self, params, grads):
+        for p, g in zip(params, grads):
+            p.grad = g
 
 
 class ShardedClipAdamW:

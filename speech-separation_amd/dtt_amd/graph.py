@@ -18,9 +18,16 @@ What the reference's loop does per step (src/trainer/trainer.py:37-72) maps to:
         loss = step(batch)            # copies the batch into the static inputs, replays
         lr_scheduler.step()           # group["lr"] is re-read before the next replay
 
-With more than one rank the recorded part ends after backward; the gradient
-exchange (GradBucketReducer.reduce_grads) and the optimizer step run behind the
-replay, eagerly.
+With more than one rank on RCCL the bucketed gradient all-reduces are recorded
+INTO the graph (``overlap_comm``): the reducer's hooks fire during the capture,
+each bucket's collective becomes a side branch of the graph that starts when the
+bucket's last gradient is written and joins ahead of the optimizer step, so the
+exchange overlaps the rest of backward exactly as in the eager path (and as
+DDP's does for the reference, trainer.py:58) and the whole step is still one
+launch.  Where collectives cannot be recorded (gloo rehearsals, or a capture
+that fails) the recorded part ends after backward; the exchange
+(GradBucketReducer.reduce_grads) and the optimizer step run behind the replay,
+eagerly.
 """
 from __future__ import annotations
 
@@ -60,11 +67,16 @@ class GraphedTrainStep:
     nest of CUDA tensors with the shapes every later batch will have."""
 
     def __init__(self, model, criterion, optimizer, inputs, batch_fn, reducer=None, warmup=2, pack_plan=None,
-                 handoff_kernels=True):
+                 handoff_kernels=True, overlap_comm=None):
         if not torch.cuda.is_available():
             raise DttError("GraphedTrainStep needs an MI355X")
         self.model, self.criterion, self.opt, self.reducer = model, criterion, optimizer, reducer
         self.world = reducer.world if reducer is not None else 1
+        if overlap_comm is None:
+            overlap_comm = os.environ.get("DTT_GRAPH_OVERLAP", "1") != "0"
+        # collectives inside the graph: RCCL only (gloo's are host-side), and the optimizer must be recordable
+        self.overlap = bool(overlap_comm and self.world > 1 and reducer is not None and reducer.capturable_collectives()
+                            and getattr(optimizer, "capturable", False))
         if not getattr(optimizer, "capturable", False) and self.world == 1:
             raise DttError("GraphedTrainStep: build the ClipAdamW with capturable=True")
         self.static_in = _clone_static(inputs)
@@ -108,13 +120,26 @@ class GraphedTrainStep:
             p.grad = None
         ops.reset_zero_arena()                             # zero-filled scratch must be born inside the capture
         if reducer is not None:
-            reducer.pause_hooks(True)
+            reducer.pause_hooks(not self.overlap)
         try:
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may query events
-                loss = self._fwd_bwd()
-                if self.world == 1:
-                    self.opt.step()
-                self.static_loss = loss.detach()
+            try:
+                self._record()
+            except Exception as e:                          # noqa: BLE001
+                if not self.overlap:
+                    raise
+                # the collectives could not be recorded on this stack: record forward + backward alone
+                import sys
+                print(f"[dtt_amd] recording the gradient all-reduces into the HIP graph failed ({type(e).__name__}: "
+                      f"{e}); exchanging behind the replay instead", file=sys.stderr, flush=True)
+                self.overlap = False
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                for p in self.params:
+                    p.grad = None
+                reducer.abort_step()
+                reducer.pause_hooks(True)
+                ops.reset_zero_arena()
+                self._record()
         finally:
             ops.reset_zero_arena()                         # later eager work must not carve from the graph's arena
             ops.handoff_kernels(prev_handoff)              # only what is RECORDED avoids the hand-off kernels
@@ -126,8 +151,17 @@ class GraphedTrainStep:
                 self._plan_keep = (ops._PLAN.outs, ops._PLAN.pairs, ops._PLAN.table)
                 ops.weight_plan(prev_plan)
         self.graph_grads = [p.grad for p in self.params]   # written in place by every replay: keep them alive
-        if self.world == 1:
+        if self.world == 1 or self.overlap:
             self.opt.note_recorded_step()                  # recording executed nothing
+
+    def _record(self):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may query events
+            loss = self._fwd_bwd()
+            if self.overlap:
+                self.reducer.finish()                      # joins the collectives' branches (stream waits, recorded)
+            if self.world == 1 or self.overlap:
+                self.opt.step()
+            self.static_loss = loss.detach()
 
     def _fwd_bwd(self):
         batch = self.batch_fn(self.static_in)
@@ -152,7 +186,7 @@ class GraphedTrainStep:
         next replay -- ``float()`` / ``.clone()`` it to keep a value."""
         if inputs is not None:
             _copy_into(self.static_in, inputs)
-        if self.world == 1:
+        if self.world == 1 or self.overlap:
             self.opt.refresh_hyper()                       # table upload with the current lr, stream-ordered
             self.graph.replay()
             self.opt.note_replayed_step()

@@ -107,5 +107,56 @@ for (k, p2), p3, w in zip(m2.named_parameters(), m3.parameters(), w0):
 print("sharded (RCCL RS/AG, one rank) vs replicated step: worst relative first-moment difference", worst_m,
       "worst parameter-step error where |gc| > 1e-6:", worst_d, "over", n_big, "tensors", flush=True)
 assert worst_m < 1e-4 and worst_d < 2e-5 and n_big > 50
+# ---- fourth leg: the bucket all-reduces recorded INTO the HIP graph (GraphedTrainStep overlap mode: what
+#      bench.py --gpus N runs on RCCL): forward + backward + collectives + clip/AdamW as one launch
+torch.manual_seed(2)
+m4 = dtt_amd.DTTNetModel(g=8, n_sources=2, n_layers=3, n_idp_layers=1, n_fft=64, hop_length=16, n_heads=2, precision="fp32").cuda()
+dist.get_world_size = lambda group=None: 2
+red4 = ddist.GradBucketReducer(m4, bucket_bytes=64 << 10)
+dist.get_world_size = real
+opt4 = dtt_amd.ClipAdamW(m4.parameters(), lr=0.0, weight_decay=0.0, max_norm=2.0, capturable=True)
+del calls[:]
+step4 = dtt_amd.GraphedTrainStep(m4, crit, opt4, {"s1": s1, "s2": s2}, batch_fn, reducer=red4, warmup=1)
+n_rec = len(calls)
+assert step4.overlap, "the collectives were not recorded into the graph (see stderr)"
+assert n_rec == 2 * len(red4.buckets), (n_rec, len(red4.buckets))        # one warm-up step + the recording
+la = float(step4({"s1": s1, "s2": s2}))
+torch.cuda.synchronize()
+lb = float(step4({"s1": s1, "s2": s2}))
+torch.cuda.synchronize()
+assert len(calls) == n_rec                                             # replays call nothing from Python
+g_graph = [p.grad.detach().clone() for p in m4.parameters()]
+assert all(p.grad.data_ptr() == v.data_ptr() for (_, ps, vs) in red4.buckets for p, v in zip(ps, vs))   # bucket views
+red4.remove()
+for p in m4.parameters():
+    p.grad = None
+b4 = batch_fn({"s1": s1, "s2": s2})
+b4.update(m4(**b4)); b4.update(crit(**b4)); b4["loss"].backward()
+torch.cuda.synchronize()
+worst4 = max(float((a - p.grad).norm() / (p.grad.norm() + 1e-12)) for a, p in zip(g_graph, m4.parameters()) if float(p.grad.norm()) > 1e-6)
+print("graph with recorded collectives: losses", la, lb, "eager", float(b4["loss"]), "worst gradient deviation", worst4, flush=True)
+assert abs(la - float(b4["loss"])) < 1e-5 * abs(la) and la == lb and worst4 < 1e-4
+# ---- fifth leg: RCCL all-reduces in flight BESIDE the hand-off LSTM kernels (lstm_rs.hip needs every workgroup of a
+#      launch co-resident, one per CU; an RCCL kernel holds CUs of the same GPU while backward runs).  The launches
+#      may stall until the collective's workgroups leave, but must not time out: the status words stay 0.
+from dtt_amd import ops
+from dtt_amd.model import IDPModule
+idp = IDPModule(2, 512).cuda()
+xi = (torch.randn(4, 33, 16, 512, device="cuda") * 0.5).to(torch.bfloat16).requires_grad_(True)
+big = torch.randn(16 << 20, device="cuda")
+ops.handoff_check()
+y0 = idp(xi).detach().clone()
+works = []
+for rep in range(6):
+    works.append(real_ar(big, op=dist.ReduceOp.AVG, async_op=True))
+    yi = idp(xi)
+    works.append(real_ar(big, op=dist.ReduceOp.AVG, async_op=True))
+    yi.float().sum().backward()
+for wk in works:
+    wk.wait()
+torch.cuda.synchronize()
+ops.handoff_check()                       # raises DttError on a timed-out hand-off
+assert torch.equal(yi.detach(), y0), "a hand-off LSTM launch beside an RCCL all-reduce returned different hidden states"
+print("hand-off LSTM kernels beside 12 RCCL all-reduces of 64 MB: status words 0, outputs bit-identical", flush=True)
 dist.destroy_process_group()
 print("rccl single-rank probe ok")

@@ -368,6 +368,38 @@ int dtt_bn_act_pool_bwd(const void* x, const void* dyp, const unsigned char* idx
                         const float* beta, float* partial, float* sums, float* dgb, void* dx, int N, int H, int W, int C,
                         int act, int training, int dtype, void* stream);
 
+/* ShuffleNetV2 units of the FiLM model's frozen lip-reading front end, forward only (lipreading/models/
+ * shufflenetv2.py:42-104 InvertedResidual, :26-40 channel_shuffle, :151-152 conv_last + globalpool; run per frame by
+ * lipreading/model.py:164-174 behind DTTNetPlus/modules/video_encoder.py:41-47).  Channels-last rows; a tensor of
+ * 2h channels is held as two halves of h channels, each padded with zero columns to hp (a multiple of 8): logical
+ * channel j is column (j / h) * hp + j % h.  The 1x1 convolutions are dtt_gemm calls on these rows.
+ *  dtt_dwconv3x3_bnrelu: depthwise 3x3, stride 1 | 2, padding 1 (shufflenetv2.py:59,69,83), x [N][H][W][C] ->
+ *    y [N][Ho][Wo][C], w9c fp32 [9 taps][C]; with stats / gamma / beta (all or none) the taps are first passed through
+ *    relu(batch_norm(.)) -- the BatchNorm + ReLU of the 1x1 conv in front (shufflenetv2.py:55-57), never written.
+ *  dtt_pw_fold_bn: the BatchNorm behind the depthwise conv (no activation, shufflenetv2.py:60,70,84) folded into the
+ *    next 1x1 conv: wout [N][K] (dtype) = w * sc[k], bias [N] = sum_k w sh[k]  (sc = gamma rstd, sh = beta - mean sc).
+ *  dtt_bn_relu_shuffle: concat + channel_shuffle(groups 2) (shufflenetv2.py:92-104) fused with the BatchNorm + ReLU
+ *    of the branch outputs: out [P][2 hp] logical channel 2i = A[i], 2i + 1 = B[i]; A / B rows of h channels with row
+ *    strides lda / ldb (elements); a source whose stats are NULL is copied as it is (the untouched half of a stride-1
+ *    unit, shufflenetv2.py:98), otherwise relu(batch_norm(.)) is applied.  Padding columns are written as zeros.
+ *  dtt_bn_relu_avgpool: BatchNorm + ReLU + AvgPool2d over the S pixels of each frame (conv_last + globalpool,
+ *    shufflenetv2.py:151-152,161-163): y [NF][S][C] -> out fp32 [NF][C]. */
+int dtt_dwconv3x3_bnrelu(const void* x, const float* w9c, const float* stats, const float* gamma, const float* beta,
+                         void* y, int N, int H, int W, int C, int stride, int dtype, void* stream);
+int dtt_pw_fold_bn(const float* w, const float* stats, const float* gamma, const float* beta, void* wout, float* bias,
+                   int N, int K, int dtype, void* stream);
+int dtt_bn_relu_shuffle(const void* a, int lda, const float* stats_a, const float* gamma_a, const float* beta_a,
+                        const void* b, int ldb, const float* stats_b, const float* gamma_b, const float* beta_b, void* out,
+                        int64_t P, int h, int hp, int dtype, void* stream);
+int dtt_bn_relu_avgpool(const void* y, const float* stats, const float* gamma, const float* beta, float* out, int NF,
+                        int S, int C, int dtype, void* stream);
+/* out[b][t][:] = linear interpolation over time of x[b][:][:] (F.interpolate(mode="linear", align_corners=False) on
+ * the time axis, the FiLM block's resampling of the video embedding, block_fusion.py:24-28, and temporal_alignment.py:
+ * 19-22): x fp32 [B][Tin][D] -> out fp32 [B][Tout][D]; the backward is the transposed gather (no atomics):
+ * dx [B][Tin][D] from dout [B][Tout][D]. */
+int dtt_lerp_time_fwd(const float* x, float* out, int B, int Tin, int Tout, int D, void* stream);
+int dtt_lerp_time_bwd(const float* dout, float* dx, int B, int Tin, int Tout, int D, void* stream);
+
 /* Gradient clip + AdamW over a table of fp32 tensors in two launches (the step after the hot path:
  * torch.optim.AdamW of train.yaml:20-23 after clip_grad_norm_ of base_trainer.py:478-490, train.yaml:59).
  * tab / chunks are device arrays; chunks[c] = {tensor index, chunk index} with chunks of

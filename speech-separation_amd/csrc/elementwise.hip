@@ -213,6 +213,55 @@ __global__ __launch_bounds__(256) void stack_frames_kernel(const float* __restri
     }
 }
 
+// Linear interpolation over time, F.interpolate(mode="linear", align_corners=False) of ATen (block_fusion.py:18-19,
+// temporal_alignment.py:19-22): source position (t + 0.5) * Tin / Tout - 0.5 clamped at 0, taps i0 = floor, i1 =
+// min(i0 + 1, Tin - 1).  x [B][Tin][D] -> out [B][Tout][D], fp32.  Backward: every input frame gathers from the output
+// frames that tap it (the taps are monotone in t; the loop over t is uniform across the workgroup): no atomics.
+__device__ __forceinline__ void lerp_taps(int t, float scale, int Tin, int& i0, int& i1, float& l1) {
+    float src = ((float)t + 0.5f) * scale - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    if (i0 > Tin - 1) i0 = Tin - 1;
+    i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+__global__ __launch_bounds__(NT) void lerp_time_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int Tin,
+                                                           int Tout, int D, float scale, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    const int d = (int)(i % D);
+    const int64_t r = i / D;
+    const int t = (int)(r % Tout);
+    const int64_t b = r / Tout;
+    int i0, i1;
+    float l1;
+    lerp_taps(t, scale, Tin, i0, i1, l1);
+    const float* xb = x + b * Tin * D + d;
+    out[i] = (1.f - l1) * xb[(int64_t)i0 * D] + l1 * xb[(int64_t)i1 * D];
+}
+__global__ __launch_bounds__(NT) void lerp_time_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int Tin,
+                                                           int Tout, int D, float scale, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    const int d = (int)(i % D);
+    const int64_t r = i / D;
+    const int ti = (int)(r % Tin);
+    const int64_t b = r / Tin;
+    const float* gb = dout + b * Tout * D + d;
+    float acc = 0.f;
+    for (int t = 0; t < Tout; ++t) {
+        int i0, i1;
+        float l1;
+        lerp_taps(t, scale, Tin, i0, i1, l1);
+        if (i0 > ti) break;                                  // taps are non-decreasing in t
+        if (i1 < ti) continue;
+        const float g = gb[(int64_t)t * D];
+        if (i0 == ti) acc += (1.f - l1) * g;
+        if (i1 == ti) acc += l1 * g;
+    }
+    dx[i] = acc;
+}
+
 }  // namespace
 
 #define ST reinterpret_cast<hipStream_t>(stream)
@@ -295,6 +344,26 @@ extern "C" int dtt_bcat_bwd(const void* dout, const float* dtok, void* dx, float
     int grid = grid_for((int64_t)B * T * C);
     if (dtype) hipLaunchKernelGGL(bcat_bwd_kernel<bf16>, dim3(grid), dim3(NT), 0, ST, (const bf16*)dout, dtok, (bf16*)dx, denh, B, F, T, C);
     else hipLaunchKernelGGL(bcat_bwd_kernel<float>, dim3(grid), dim3(NT), 0, ST, (const float*)dout, dtok, (float*)dx, denh, B, F, T, C);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_lerp_time_fwd(const float* x, float* out, int B, int Tin, int Tout, int D, void* stream) {
+    DTT_CHECK(x && out && B > 0 && Tin > 0 && Tout > 0 && D > 0, "dtt_lerp_time_fwd: bad arguments");
+    const int64_t total = (int64_t)B * Tout * D;
+    DTT_CHECK((total + NT - 1) / NT < (1LL << 31), "dtt_lerp_time_fwd: too large");
+    hipLaunchKernelGGL(lerp_time_fwd_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0,
+                       static_cast<hipStream_t>(stream), x, out, Tin, Tout, D, (float)Tin / (float)Tout, total);
+    DTT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dtt_lerp_time_bwd(const float* dout, float* dx, int B, int Tin, int Tout, int D, void* stream) {
+    DTT_CHECK(dout && dx && B > 0 && Tin > 0 && Tout > 0 && D > 0, "dtt_lerp_time_bwd: bad arguments");
+    const int64_t total = (int64_t)B * Tin * D;
+    DTT_CHECK((total + NT - 1) / NT < (1LL << 31), "dtt_lerp_time_bwd: too large");
+    hipLaunchKernelGGL(lerp_time_bwd_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0,
+                       static_cast<hipStream_t>(stream), dout, dx, Tin, Tout, D, (float)Tin / (float)Tout, total);
     DTT_LAUNCH_CHECK();
     return 0;
 }

@@ -2,8 +2,10 @@
 
 Big-tensor work (frequency-mean tokens, FiLM apply, broadcast + concat, 1x1
 projection) runs in the HIP kernels; the token-level network (<= 50 tokens per
-item, 0.08-0.26 GFLOP/sample) is plain fp32 library GEMMs
-(rocBLAS through torch) plus elementwise ops on [B, <=50, C] tensors.
+item, 0.08-0.26 GFLOP/sample) runs its Linear layers through
+dtt_gemm (ops.Linear, exact-fp32 MFMA), its attention core on attn.hip and the
+resampling of the video embedding on dtt_lerp_time; LayerNorm, GELU, concatenation
+and residual adds are elementwise torch ops on [B, <= 150, C] tensors.
 
 Reference: src/model/VideoAudioFusions/{cross_attention_positional,
 temporal_alignment}.py, src/model/DTTNetPlus/blocks/block_fusion.py.
@@ -105,12 +107,11 @@ class TemporalAligner(nn.Module):
         B, Fq, T, Cc = audio_features.shape
         _, Cv, Ev, Tv = video_features.shape
         with torch.autocast("cuda", enabled=False):
-            v = video_features.float().reshape(B, Cv * Ev, Tv)
+            v = video_features.float().reshape(B, Cv * Ev, Tv).transpose(1, 2)
             w = self.video_projection.weight.reshape(Cc, Cv * Ev)
-            vp = torch.einsum("oc,bct->bot", w, v) + self.video_projection.bias[None, :, None]
+            vp = ops.Linear.apply(v, w, self.video_projection.bias, False)          # [B,Tv,C]
             if Tv != T:
-                vp = F.interpolate(vp, size=T, mode="linear", align_corners=False)
-            vp = vp.transpose(1, 2).contiguous()                      # [B,T,C]
+                vp = ops.LerpTime.apply(vp, T)                                      # [B,T,C]
         a = ops.Conv1x1.apply(audio_features, self.audio_projection.weight, self.audio_projection.bias)
         return ops.BroadcastConcat.apply(a, vp)
 
@@ -119,7 +120,11 @@ def film_apply(block, x, video):
     """FusionBlock.forward (block_fusion.py:16-37): x [B,F,T,C] channels-last, video [B,T_v,D]."""
     T = x.shape[2]
     with torch.autocast("cuda", enabled=False):
-        v = F.interpolate(video.float().transpose(-1, -2), size=T, mode="linear").transpose(-1, -2)   # [B,T,D]
-        gbc = torch.cat([block.w_gamma_channels(v), block.w_beta_channels(v)], dim=-1)              # [B,T,2C]
-        gbf = torch.cat([block.w_gamma_freq(v), block.w_beta_freq(v)], dim=-1)                      # [B,T,2F]
+        v = video.float()
+        v = ops.LerpTime.apply(v, T) if v.shape[1] != T else v                                      # [B,T,D]
+        lin = ops.Linear.apply
+        gc, bc, gf, bf = (lin(v, m.weight, m.bias, False) for m in
+                          (block.w_gamma_channels, block.w_beta_channels, block.w_gamma_freq, block.w_beta_freq))
+        gbc = torch.cat([gc, bc], dim=-1)                                                           # [B,T,2C]
+        gbf = torch.cat([gf, bf], dim=-1)                                                           # [B,T,2F]
     return ops.Film.apply(x, gbc, gbf)

@@ -388,7 +388,8 @@ class DTTNetPlusModel(_SeparatorBase):
             elif video_features.dim() != 3 or video_features.shape[-1] != 2048:
                 raise DttError("video_features must be [B, T_v, 2048]")
             with torch.autocast("cuda", enabled=False):
-                video_encoded = self.video_encoder.post_processor(video_features.float())
+                pp = self.video_encoder.post_processor          # trainable Linear(2048 -> D), fp32, through dtt_gemm
+                video_encoded = ops.Linear.apply(video_features.float(), pp.weight, pp.bias, False)
             if _Tap.store is not None:
                 _Tap.store["video_encoder"] = video_encoded.detach().float()
         x = self.latent(x, video_encoded)

@@ -1494,6 +1494,30 @@ class Conv1x1NormGelu(torch.autograd.Function):
         return (dx.view_as(x) if dx is not None else None), dw.view(ctx.wshape), db
 
 
+class LerpTime(torch.autograd.Function):
+    """F.interpolate(x.transpose(-1, -2), size=T, mode="linear").transpose(-1, -2) for x fp32 [B, T_in, D]
+    (block_fusion.py:18-19; temporal_alignment.py:19-22, where the bilinear resize of a tensor constant over F is this
+    interpolation over time): ATen's kernel walks batch x channel serially per output frame -- 4.3 ms forward and
+    9.7 ms backward (atomics) at [64, 512, 50 -> 16] -- these are one gather pass each way."""
+
+    @staticmethod
+    def forward(ctx, x, T):
+        x = x.contiguous().float()
+        B, Tin, D = x.shape
+        out = _empty((B, T, D), F32, x.device)
+        check(lib().dtt_lerp_time_fwd(ptr(x), ptr(out), B, Tin, T, D, stream_ptr()), "dtt_lerp_time_fwd")
+        ctx.dims = (B, Tin, T, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Tin, T, D = ctx.dims
+        dout = dout.contiguous().float()
+        dx = _empty((B, Tin, D), F32, dout.device)
+        check(lib().dtt_lerp_time_bwd(ptr(dout), ptr(dx), B, Tin, T, D, stream_ptr()), "dtt_lerp_time_bwd")
+        return dx, None
+
+
 class Film(torch.autograd.Function):
     """(1 + gamma_c + gamma_f) * x + beta_c + beta_f  (block_fusion.py:30-37).
     gbc [B,T,2C] = (gamma_c | beta_c), gbf [B,T,2F] = (gamma_f | beta_f), fp32."""

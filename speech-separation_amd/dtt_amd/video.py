@@ -5,7 +5,8 @@ resnet_video_encoder.py:46-60).  ResNet-18 encoder: every stage runs on the HIP 
 (ops.MaxPool3x3s2), the trunk's 3x3 convolutions of either stride (ops.Conv3x3) and its 1x1 stride-2 downsample
 convolutions (ops.Conv1x1s2): no library convolution is left in the step.  Switches for A/B runs:
 DTT_VIDEO_OWN_CONV=0 (all convolutions on MIOpen), DTT_VIDEO_FRONT_CONV=0, DTT_VIDEO_S2_CONV=0 (only those).
-ShuffleNetV2 encoder (FiLM model): stock modules.
+ShuffleNetV2 encoder (FiLM model, frozen): the same front-end kernels, then the units on lipnet.py / lipunit.hip
+(DTT_LIP_OWN=0: stock modules).
 
 Reference: src/model/VideoEncoders/{resnet,resnet_video_encoder}.py.
 """
@@ -26,6 +27,7 @@ _OWN_FRONT = os.environ.get("DTT_VIDEO_FRONT_CONV", "1") == "1"   # 0: only the 
 
 _FUSED_POOL = os.environ.get("DTT_VIDEO_FUSED_POOL", "1") == "1"   # 0: front-end BatchNorm + Swish and max pool as two ops
 _OWN_S2 = os.environ.get("DTT_VIDEO_S2_CONV", "1") == "1"         # 0: the trunk's stride-2 3x3 and 1x1 convolutions on MIOpen
+_LIP_OWN = os.environ.get("DTT_LIP_OWN", "1") == "1"              # 0: the ShuffleNetV2 lip front end on the stock modules (A/B switch)
 
 
 def _conv3x3(conv, x, slot=None):
@@ -149,6 +151,53 @@ class ResNet18Trunk(nn.Module):
         return self.avgpool(x).flatten(1)
 
 
+def frontend_fused(frontend3D, x, act):
+    """frontend3D (Conv3d + BatchNorm3d + activation + MaxPool3d; act 1 swish: resnet_video_encoder.py:33-44, 2 relu:
+    lipreading/model.py:126-131) on the HIP path.  With one input channel, Conv3d((5,7,7), stride (1,2,2), padding
+    (2,3,3)) is a per-frame Conv2d over the 5 neighbouring frames stacked as channels (zero frames beyond the clip's
+    ends), so its output is born as [frames, Co, 44, 44] in channels-last memory: no im2col of a 3-d volume, no
+    layout change towards the 2-d trunk.  BatchNorm3d's statistics over (N, D, H, W) are BatchNorm2d's over
+    (N * D, H, W); BN + activation and the (1,3,3) max pool run on the fused kernels."""
+    from .ops import batch_norm_act, batch_norm_act_pool, MaxPool3x3s2
+
+    def bn_pool(y):
+        if _FUSED_POOL:
+            return batch_norm_act_pool(y, bn, act)
+        return MaxPool3x3s2.apply(batch_norm_act(y, bn, act))
+    conv, bn = frontend3D[0], frontend3D[1]
+    Bp, _, T, H, W = x.shape
+    kt = conv.kernel_size[0]
+    w2 = conv.weight[:, 0]                                                    # [64, 5, 7, 7]
+    cpad = (-kt) % 8                                                          # channel count to a multiple of 8
+    if kt <= 8 and kt % 2 == 1 and x.dtype == torch.float32 and not x.requires_grad:
+        # one pass: fp32 clip -> stacked, channel-padded, channels-last frames in the conv's dtype (the torch
+        # route below is five copies of a 200 MB tensor: pad, unfold, channel pad, layout, autocast)
+        from . import ops
+        odt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        if odt not in (torch.bfloat16, torch.float32):
+            odt = torch.float32
+        own = (_OWN_CONV and _OWN_FRONT and conv.kernel_size[1:] == (7, 7) and conv.stride == (1, 2, 2) and conv.padding[1:] == (3, 3)
+               and H % 2 == 0 and W % 2 == 0)
+        padl, padr = (3, 5) if own else (0, 0)         # own conv: zero columns instead of per-pixel predicates
+        buf = torch.empty((Bp * T, H, padl + W + padr, 8), dtype=odt, device=x.device)
+        ops.check(ops.lib().dtt_stack_frames(ops.ptr(x.contiguous()), ops.ptr(buf), Bp, T, H, W, kt, padl, padr,
+                                             1 if odt == torch.bfloat16 else 0, ops.stream_ptr()), "dtt_stack_frames")
+        if own:
+            y = ops.FrontConv.apply(buf, conv.weight, H, W).permute(0, 3, 1, 2)   # NCHW view of channels-last memory
+            return bn_pool(y), T
+        x5 = buf.permute(0, 3, 1, 2)                                          # NCHW view of channels-last memory
+    else:
+        xp = nn.functional.pad(x[:, 0], (0, 0, 0, 0, kt // 2, kt // 2))        # [B', T + 4, H, W]
+        x5 = xp.unfold(1, kt, 1).permute(0, 1, 4, 2, 3).reshape(Bp * T, kt, H, W)   # frames t-2 .. t+2 as channels
+        if cpad:
+            x5 = nn.functional.pad(x5, (0, 0, 0, 0, 0, cpad))
+        x5 = x5.contiguous(memory_format=torch.channels_last)
+    if cpad:
+        w2 = nn.functional.pad(w2, (0, 0, 0, 0, 0, cpad))
+    y = nn.functional.conv2d(x5, w2, None, stride=conv.stride[1:], padding=conv.padding[1:])
+    return bn_pool(y), T
+
+
 class VideoEncoder(nn.Module):
     """resnet_video_encoder.py:22-72: Conv3d(5,7,7)+BN3d+Swish+MaxPool3d -> ResNet-18.
     video [B, N, T, H, W] -> [B, N, 512, T]."""
@@ -166,49 +215,7 @@ class VideoEncoder(nn.Module):
             self.load_state_dict(ck["model_state_dict"], strict=False)
 
     def _frontend_fused(self, x):
-        """frontend3D on the HIP path.  With one input channel, Conv3d((5,7,7), stride (1,2,2), padding (2,3,3)) is a
-        per-frame Conv2d over the 5 neighbouring frames stacked as channels (zero frames beyond the clip's ends), so
-        its output is born as [frames, 64, 44, 44] in channels-last memory: no im2col of a 3-d volume, no layout
-        change towards the 2-d trunk.  BatchNorm3d's statistics over (N, D, H, W) are BatchNorm2d's over
-        (N * D, H, W); BN + Swish and the (1,3,3) max pool run on the fused kernels."""
-        from .ops import batch_norm_act, batch_norm_act_pool, MaxPool3x3s2
-
-        def bn_pool(y):
-            if _FUSED_POOL:
-                return batch_norm_act_pool(y, bn, 1)
-            return MaxPool3x3s2.apply(batch_norm_act(y, bn, 1))
-        conv, bn = self.frontend3D[0], self.frontend3D[1]
-        Bp, _, T, H, W = x.shape
-        kt = conv.kernel_size[0]
-        w2 = conv.weight[:, 0]                                                    # [64, 5, 7, 7]
-        cpad = (-kt) % 8                                                          # channel count to a multiple of 8
-        if kt <= 8 and kt % 2 == 1 and x.dtype == torch.float32 and not x.requires_grad:
-            # one pass: fp32 clip -> stacked, channel-padded, channels-last frames in the conv's dtype (the torch
-            # route below is five copies of a 200 MB tensor: pad, unfold, channel pad, layout, autocast)
-            from . import ops
-            odt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
-            if odt not in (torch.bfloat16, torch.float32):
-                odt = torch.float32
-            own = (_OWN_CONV and _OWN_FRONT and conv.kernel_size[1:] == (7, 7) and conv.stride == (1, 2, 2) and conv.padding[1:] == (3, 3)
-                   and H % 2 == 0 and W % 2 == 0)
-            padl, padr = (3, 5) if own else (0, 0)         # own conv: zero columns instead of per-pixel predicates
-            buf = torch.empty((Bp * T, H, padl + W + padr, 8), dtype=odt, device=x.device)
-            ops.check(ops.lib().dtt_stack_frames(ops.ptr(x.contiguous()), ops.ptr(buf), Bp, T, H, W, kt, padl, padr,
-                                                 1 if odt == torch.bfloat16 else 0, ops.stream_ptr()), "dtt_stack_frames")
-            if own:
-                y = ops.FrontConv.apply(buf, conv.weight, H, W).permute(0, 3, 1, 2)   # NCHW view of channels-last memory
-                return bn_pool(y), T
-            x5 = buf.permute(0, 3, 1, 2)                                          # NCHW view of channels-last memory
-        else:
-            xp = nn.functional.pad(x[:, 0], (0, 0, 0, 0, kt // 2, kt // 2))        # [B', T + 4, H, W]
-            x5 = xp.unfold(1, kt, 1).permute(0, 1, 4, 2, 3).reshape(Bp * T, kt, H, W)   # frames t-2 .. t+2 as channels
-            if cpad:
-                x5 = nn.functional.pad(x5, (0, 0, 0, 0, 0, cpad))
-            x5 = x5.contiguous(memory_format=torch.channels_last)
-        if cpad:
-            w2 = nn.functional.pad(w2, (0, 0, 0, 0, 0, cpad))
-        y = nn.functional.conv2d(x5, w2, None, stride=conv.stride[1:], padding=conv.padding[1:])
-        return bn_pool(y), T
+        return frontend_fused(self.frontend3D, x, 1)
 
     def forward(self, x):
         B, N, T, H, W = x.shape
@@ -295,8 +302,27 @@ class LipReadingEncoder(nn.Module):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
 
+    def _own_kernels(self, x):
+        """The HIP path takes the reference's geometry (one-channel fp32 clips whose trunk output is 3 x 3: 88 x 88 lip
+        crops) when no gradient is wanted (the encoder is frozen, video_encoder.py:38-39); anything else runs on the
+        stock modules below."""
+        if not (_LIP_OWN and _FUSED_BN and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()):
+            return False
+        H, W = x.shape[3], x.shape[4]
+        if x.shape[1] != 1 or H % 2 or W % 2:
+            return False
+        for _ in range(5):                                    # stem conv, max pool, three stride-2 units
+            H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        return (H, W) == (3, 3)
+
     def forward(self, x, lengths=None):
         Bp = x.shape[0]
+        if self._own_kernels(x):
+            from . import lipnet
+            y, Tn = frontend_fused(self.frontend3D, x, 2)                       # [B' T, 24, 22, 22], channels-last memory
+            NF, Cc, H, W = y.shape
+            rows = y.permute(0, 2, 3, 1).contiguous().view(NF * H * W, Cc)
+            return lipnet.trunk_forward(self, rows, NF, H, W).view(Bp, Tn, -1)
         x = self.frontend3D(x)
         Tn = x.shape[2]
         x = x.transpose(1, 2).reshape(Bp * Tn, x.shape[1], x.shape[3], x.shape[4])
@@ -333,4 +359,9 @@ class VideoEncoderModule(nn.Module):
         return out.transpose(1, 2).flatten(-2, -1).float()
 
     def forward(self, video, bf16=False):
-        return self.post_processor(self.features(video, bf16))
+        feats = self.features(video, bf16)
+        if feats.is_cuda:                      # the trainable projection (video_encoder.py:33,46) through dtt_gemm, fp32
+            from .ops import Linear
+            with torch.autocast("cuda", enabled=False):
+                return Linear.apply(feats, self.post_processor.weight, self.post_processor.bias, False)
+        return self.post_processor(feats)

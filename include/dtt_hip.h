@@ -341,6 +341,10 @@ int dtt_xattn_bwd(const float* q, const float* k, const float* v, const float* p
  * [C][2] floats of scratch.  dtt_bn_running: nn.BatchNorm's running-statistics update (unbiased variance). */
 int dtt_bn_chunks(int P);
 int dtt_bn_stats(const void* x, float* partial, float* stats, int P, int C, float eps, int dtype, void* stream);
+/* dtt_bn_stats with the running-buffer update in the same launches; a tensor held as halves of h channels padded to hp
+ * columns (the ShuffleNetV2 layout below) updates logical channel (c / hp) * h + c % hp; dense: h = hp = C. */
+int dtt_bn_stats_running(const void* x, float* partial, float* stats, int P, int C, float eps, int dtype,
+                         float* running_mean, float* running_var, float momentum, int h, int hp, void* stream);
 int dtt_bn_act_fwd(const void* x, const void* res, const float* stats, const float* gamma, const float* beta, void* z,
                    int P, int C, int act, int dtype, void* stream);
 int dtt_bn_act_bwd(const void* x, const void* res, const void* dz, const float* stats, const float* gamma,

@@ -144,8 +144,11 @@ __global__ __launch_bounds__(NT) void bn_stats_partial(const T* __restrict__ x, 
 // fixed-order merge of the FG (a single serial walk over ~500 chunks per channel cost 270 us per BatchNorm, 8
 // groups 21 us, 32 groups of a 1024-thread workgroup ~8); stats[c] = {mean, rstd}
 constexpr int FG = 32;
+// run: the running-buffer update of nn.BatchNorm in the same launch (NULL buffers: none).  Column c of a tensor held as
+// halves of h channels padded to hp (lipunit.hip) is logical channel (c / hp) * h + c % hp; dense tensors pass h = hp = C.
+struct BnRun { float* rmean; float* rvar; float momentum; int h, hp; };
 __global__ __launch_bounds__(32 * FG) void bn_stats_finalize(const float* __restrict__ partial, float* __restrict__ stats, int P,
-                                                         int C, int chunk, int nchunks, float eps) {
+                                                         int C, int chunk, int nchunks, float eps, BnRun run) {
     __shared__ float sh[3][FG][33];
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -175,6 +178,15 @@ __global__ __launch_bounds__(32 * FG) void bn_stats_finalize(const float* __rest
         }
         stats[c * 2] = tm;
         stats[c * 2 + 1] = rsqrtf(t2 / tn + eps);
+        if (run.rmean) {
+            const int half = c / run.hp, pos = c - half * run.hp;
+            if (pos < run.h) {
+                const int lc = half * run.h + pos;
+                const float unb = t2 / tn * (tn > 1.f ? tn / (tn - 1.f) : 1.f);
+                run.rmean[lc] = (1.f - run.momentum) * run.rmean[lc] + run.momentum * tm;
+                run.rvar[lc] = (1.f - run.momentum) * run.rvar[lc] + run.momentum * unb;
+            }
+        }
     }
 }
 
@@ -537,7 +549,18 @@ static int bn_check(int P, int C, int dtype, const char* what) {
 
 // Batch statistics over all P pixels: stats [C][2] = {mean, rstd} (biased variance + eps, as nn.BatchNorm normalises);
 // partial: dtt_bn_chunks(P) * C * 2 floats of scratch.
+static int bn_stats_launch(const void* x, float* partial, float* stats, int P, int C, float eps, int dtype, BnRun run, void* stream);
 extern "C" int dtt_bn_stats(const void* x, float* partial, float* stats, int P, int C, float eps, int dtype, void* stream) {
+    return bn_stats_launch(x, partial, stats, P, C, eps, dtype, BnRun{nullptr, nullptr, 0.f, C, C}, stream);
+}
+// ... and the running-buffer update (momentum form, unbiased variance) in the same launches; h / hp: the halves layout
+// of lipunit.hip (h = hp = C for a dense tensor)
+extern "C" int dtt_bn_stats_running(const void* x, float* partial, float* stats, int P, int C, float eps, int dtype,
+                                    float* running_mean, float* running_var, float momentum, int h, int hp, void* stream) {
+    DTT_CHECK(running_mean && running_var && h > 0 && hp >= h && C % hp == 0, "dtt_bn_stats_running: bad arguments");
+    return bn_stats_launch(x, partial, stats, P, C, eps, dtype, BnRun{running_mean, running_var, momentum, h, hp}, stream);
+}
+static int bn_stats_launch(const void* x, float* partial, float* stats, int P, int C, float eps, int dtype, BnRun run, void* stream) {
     if (int rc = bn_check(P, C, dtype, "dtt_bn_stats")) return rc;
     DTT_CHECK(x && partial && stats, "dtt_bn_stats: bad arguments");
     const int chunk = bn_chunk(P), nch = (P + chunk - 1) / chunk;
@@ -545,7 +568,7 @@ extern "C" int dtt_bn_stats(const void* x, float* partial, float* stats, int P, 
     const size_t sm = (size_t)(NT * ept + C) * sizeof(float);
     if (dtype) hipLaunchKernelGGL(bn_stats_partial<bf16>, dim3(nch), dim3(NT), sm, ST, (const bf16*)x, partial, P, C, chunk);
     else hipLaunchKernelGGL(bn_stats_partial<float>, dim3(nch), dim3(NT), sm, ST, (const float*)x, partial, P, C, chunk);
-    hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 31) / 32), dim3(32 * FG), 0, ST, partial, stats, P, C, chunk, nch, eps);
+    hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 31) / 32), dim3(32 * FG), 0, ST, partial, stats, P, C, chunk, nch, eps, run);
     DTT_LAUNCH_CHECK();
     return 0;
 }

@@ -20,56 +20,83 @@
 namespace {
 constexpr int NT = 256;
 
-template <typename T>
+// One thread owns a 16-byte channel chunk of one output COLUMN of one frame and walks down the output rows with a
+// 3-row window of the input in registers: the nine tap weights and the BatchNorm constants are loaded once per thread
+// (per-output threads re-read them for every pixel: 350 bytes of L1 traffic per 16 bytes written), each input vector
+// once per column triple, and the next row's loads are issued before the current row is summed.  Lanes run over
+// (column, chunk): a wave reads contiguous spans of an image row.
+template <typename T, int STRIDE>
 __global__ __launch_bounds__(NT) void dw3x3_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, T* __restrict__ y, int H, int W, int C,
-                                                   int stride, int Ho, int Wo, int64_t total) {
-    constexpr int EPT = Vec16<T>::N;
+                                                   int Ho, int Wo, int total) {
+    constexpr int EPT = Vec16<T>::N, NEW = STRIDE;         // input rows that enter the window per output row
     const int cpp = C / EPT;
-    const int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int idx = blockIdx.x * NT + threadIdx.x;
     if (idx >= total) return;
-    const int cq = (int)(idx % cpp);
-    int64_t pix = idx / cpp;
-    const int wo = (int)(pix % Wo);
-    pix /= Wo;
-    const int ho = (int)(pix % Ho);
-    const int64_t n = pix / Ho;
+    const int cq = idx % cpp, r = idx / cpp, wo = r % Wo, n = r / Wo;
     const bool pre = stats != nullptr;
-    float sc[EPT], sh[EPT];
+    float sc[EPT], sh[EPT], wr[9][EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int c = cq * EPT + e;
         sc[e] = pre ? gamma[c] * stats[c * 2 + 1] : 1.f;
         sh[e] = pre ? beta[c] - stats[c * 2] * sc[e] : 0.f;
     }
-    const int h0 = ho * stride - 1, w0 = wo * stride - 1;
-    const T* xb = x + cq * EPT;
-    Vec16<T> v[9];
-    bool ok[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int hh = h0 + k / 3, ww = w0 + k % 3;
-        ok[k] = hh >= 0 && hh < H && ww >= 0 && ww < W;
-        v[k] = ld16_pred<T>(xb + ((n * H + hh) * W + ww) * C, xb, ok[k]);
-    }
-    float acc[EPT];
+    for (int k = 0; k < 9; ++k)
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
+        for (int e = 0; e < EPT; ++e) wr[k][e] = w[k * C + cq * EPT + e];
+    const int w0 = wo * STRIDE - 1;
+    bool okw[3];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const float* wk = w + k * C + cq * EPT;
+    for (int kw = 0; kw < 3; ++kw) okw[kw] = w0 + kw >= 0 && w0 + kw < W;
+    const T* xb = x + (int64_t)n * H * W * C + cq * EPT;
+    T* yb = y + ((int64_t)n * Ho * Wo + wo) * C + cq * EPT;
+    Vec16<T> win[3][3], nx[NEW][3];
+    bool rok[3], nok[NEW];
+    auto load_row = [&](int hh, Vec16<T> (&dst)[3], bool& ok) {
+        ok = hh >= 0 && hh < H;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            float a = v[k].get(e);
-            if (pre) a = fmaxf(a * sc[e] + sh[e], 0.f);
-            acc[e] += ok[k] ? a * wk[e] : 0.f;              // zero padding is applied to the ACTIVATED input
+        for (int kw = 0; kw < 3; ++kw) dst[kw] = ld16_pred<T>(xb + ((int64_t)hh * W + w0 + kw) * C, xb, ok && okw[kw]);
+    };
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) load_row(kh - 1, win[kh], rok[kh]);
+    for (int ho = 0; ho < Ho; ++ho) {
+#pragma unroll
+        for (int i = 0; i < NEW; ++i) load_row((ho + 1) * STRIDE - 1 + (3 - NEW) + i, nx[i], nok[i]);   // next window's new rows
+        float acc[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const bool ok = rok[kh] && okw[kw];          // zero padding is applied to the ACTIVATED input
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    float a = win[kh][kw].get(e);
+                    if (pre) a = fmaxf(a * sc[e] + sh[e], 0.f);
+                    acc[e] += ok ? a * wr[kh * 3 + kw][e] : 0.f;
+                }
+            }
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) o.set(e, acc[e]);
+        st16<T>(yb + (int64_t)ho * Wo * C, o);
+#pragma unroll
+        for (int kh = 0; kh < 3 - NEW; ++kh) {
+            rok[kh] = rok[kh + NEW];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) win[kh][kw] = win[kh + NEW][kw];
+        }
+#pragma unroll
+        for (int i = 0; i < NEW; ++i) {
+            rok[3 - NEW + i] = nok[i];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) win[3 - NEW + i][kw] = nx[i][kw];
         }
     }
-    Vec16<T> o;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) o.set(e, acc[e]);
-    st16<T>(y + idx * EPT, o);
 }
 
 struct ShufP {
@@ -201,16 +228,15 @@ extern "C" int dtt_dwconv3x3_bnrelu(const void* x, const float* w9c, const float
               "dtt_dwconv3x3_bnrelu: stats, gamma and beta go together");
     DTT_CHECK(al16(x) && al16(y) && al16(w9c), "dtt_dwconv3x3_bnrelu: operands must be 16-byte aligned");
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    const int64_t total = (int64_t)N * Ho * Wo * (C / ept);
-    DTT_CHECK((total + NT - 1) / NT < (1LL << 31), "dtt_dwconv3x3_bnrelu: too many pixels");
+    const int64_t total = (int64_t)N * Wo * (C / ept);
+    DTT_CHECK(total < (1LL << 31) && (int64_t)H * W * C < (1LL << 31), "dtt_dwconv3x3_bnrelu: too many columns");
     const dim3 grid((unsigned)((total + NT - 1) / NT));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == 1)
-        hipLaunchKernelGGL(dw3x3_kernel<bf16>, grid, dim3(NT), 0, st, static_cast<const bf16*>(x), w9c, stats, gamma, beta,
-                           static_cast<bf16*>(y), H, W, C, stride, Ho, Wo, total);
-    else
-        hipLaunchKernelGGL(dw3x3_kernel<float>, grid, dim3(NT), 0, st, static_cast<const float*>(x), w9c, stats, gamma, beta,
-                           static_cast<float*>(y), H, W, C, stride, Ho, Wo, total);
+#define DTT_DW(T, S) hipLaunchKernelGGL((dw3x3_kernel<T, S>), grid, dim3(NT), 0, st, static_cast<const T*>(x), w9c, stats, gamma, \
+                                         beta, static_cast<T*>(y), H, W, C, Ho, Wo, (int)total)
+    if (dtype == 1) { if (stride == 1) DTT_DW(bf16, 1); else DTT_DW(bf16, 2); }
+    else { if (stride == 1) DTT_DW(float, 1); else DTT_DW(float, 2); }
+#undef DTT_DW
     DTT_LAUNCH_CHECK();
     return 0;
 }

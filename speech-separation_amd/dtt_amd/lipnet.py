@@ -12,7 +12,7 @@ How a unit runs (lipunit.hip has the layout and the kernels):
   BN behind the depthwise conv   folded into the next 1x1 conv's weights + a bias (dtt_pw_fold_bn)
   BN + ReLU + concat + channel_shuffle   one pass (dtt_bn_relu_shuffle)
   conv_last's BN + ReLU + AvgPool2d(3)   one pass (dtt_bn_relu_avgpool)
-Batch statistics: dtt_bn_stats over the raw conv output (bn_act.hip), running buffers by dtt_bn_running.
+Batch statistics and the running-buffer update: dtt_bn_stats_running over the raw conv output (bn_act.hip).
 The weights are frozen, so their channel-padded copies are built once per (device, dtype) and rebuilt only when a
 parameter's version counter moves (load_state_dict).
 """
@@ -145,16 +145,18 @@ class _Run:
         if bn.training or not bn.track_running_stats:
             stats = torch.empty((Cp, 2), dtype=F32, device=self.dev)
             part = torch.empty((lib().dtt_bn_chunks(P), Cp, 2), dtype=F32, device=self.dev)
-            check(lib().dtt_bn_stats(ptr(y), ptr(part), ptr(stats), P, Cp, C.c_float(bn.eps), self.d, stream_ptr()), "dtt_bn_stats")
             if bn.training and bn.track_running_stats and bn.running_mean is not None:
                 if bn.momentum is None:
                     raise DttError("lipnet: BatchNorm momentum=None (cumulative average) is not supported")
-                for po, lo, n in b.lay.segs:
-                    check(lib().dtt_bn_running(ptr(stats[po:]), ptr(bn.running_mean[lo:]), ptr(bn.running_var[lo:]), n,
-                                               C.c_int64(P), C.c_float(bn.momentum), C.c_float(bn.eps), stream_ptr()),
-                          "dtt_bn_running")
+                h, hp = (b.lay.h, b.lay.hp) if len(b.lay.segs) == 2 else (Cp, Cp)
+                check(lib().dtt_bn_stats_running(ptr(y), ptr(part), ptr(stats), P, Cp, C.c_float(bn.eps), self.d,
+                                                 ptr(bn.running_mean), ptr(bn.running_var), C.c_float(bn.momentum), h, hp,
+                                                 stream_ptr()), "dtt_bn_stats_running")
                 if bn.num_batches_tracked is not None:
                     self.tracked.append(bn.num_batches_tracked)
+            else:
+                check(lib().dtt_bn_stats(ptr(y), ptr(part), ptr(stats), P, Cp, C.c_float(bn.eps), self.d, stream_ptr()),
+                      "dtt_bn_stats")
             return stats
         stats = torch.zeros((Cp, 2), dtype=F32, device=self.dev)
         for po, lo, n in b.lay.segs:

@@ -96,7 +96,26 @@ def _ew(idx, ntensors, dt_idx):
     return f
 
 
+def _dwconv(args):
+    N, H, W, Cc, stride = (_v(args[i]) for i in range(6, 11))
+    es = _es(_v(args[11]))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    return dict(N=N, H=H, W=W, C=Cc, stride=stride), 0.0, N * Cc * (H * W + Ho * Wo) * es
+
+
+def _shuffle(args):
+    P, h, hp = (_v(args[i]) for i in range(11, 14))
+    es = _es(_v(args[14]))
+    return dict(P=P, h=h, hp=hp), 0.0, P * (2 * h + 2 * hp) * es
+
+
+def _avgpool(args):
+    NF, S, Cc = (_v(args[i]) for i in range(5, 8))
+    return dict(NF=NF, S=S, C=Cc), 0.0, NF * S * Cc * _es(_v(args[8])) + NF * Cc * 4
+
+
 SPECS = {
+    "dtt_dwconv3x3_bnrelu": _dwconv, "dtt_bn_relu_shuffle": _shuffle, "dtt_bn_relu_avgpool": _avgpool,
     "dtt_gemm": _gemm,
     "dtt_conv3x3_s1": _conv3(7, 13),
     "dtt_conv3x3_wgrad": _conv3(3, None),
@@ -107,7 +126,7 @@ SPECS = {
     "dtt_in_gelu_fwd": _ew(dict(B=3, F=4, T=5, C=8), 2, 9),            # read y, write z
     "dtt_in_gelu_bwd": _ew(dict(B=6, F=7, T=8, C=11), 3, 13),          # read y, dz; write dy (its two sweeps re-read)
     "dtt_in_stats": _ew(dict(B=3, P=4, C=5), 1, 8),
-    "dtt_bn_stats": _ew(dict(P=3, C=4), 1, 6),
+    "dtt_bn_stats": _ew(dict(P=3, C=4), 1, 6), "dtt_bn_stats_running": _ew(dict(P=3, C=4), 1, 6),
     "dtt_bn_act_fwd": _ew(dict(P=6, C=7), 2, 9),
     "dtt_bn_act_bwd": _ew(dict(P=11, C=12), 3, 15),
     "dtt_bn_act_pool_fwd": _ew(dict(N=6, H=7, W=8, C=9), 1.25, 11),

@@ -401,7 +401,7 @@ def step_roofline(w, cfg, B, precision, workload):
         e = r["entry"]
         k = ("lstm recurrence" if "lstm" in e else "3x3 conv (tile kernels)" if e == "dtt_conv3x3_s1" else
              "3x3 conv weight gradient (tile kernels)" if "wgrad" in e else "gemm (Linear / implicit-GEMM conv / DFT)" if e == "dtt_gemm"
-             else "InstanceNorm + GELU" if "in_gelu" in e or e == "dtt_in_stats" else "BatchNorm / pool (lip encoder)" if "bn_" in e or "pool" in e
+             else "InstanceNorm + GELU" if "in_gelu" in e or e == "dtt_in_stats" else "BatchNorm / pool / depthwise (lip encoder)" if "bn_" in e or "pool" in e or "dwconv" in e or "pw_fold" in e
              else "other entry points")
         fam[k] = round(fam.get(k, 0.0) + r["ms_per_step"], 3)
     fam["outside entry points (torch glue, launch gaps of the eager issue)"] = tab["outside_entry_points_ms_per_step"]

@@ -178,7 +178,7 @@ def build_workload(name, args, dev, rank, world, reducer_cls):
         opt.step()
         return batch["loss"]
 
-    mode, step = "eager", eager_step
+    mode, step, gs = "eager", eager_step, None
     if use_graph:
         try:
             gs = dtt_amd.GraphedTrainStep(model, criterion, opt, pool[0], batch_fn, reducer=reducer, warmup=2)
@@ -198,7 +198,45 @@ def build_workload(name, args, dev, rank, world, reducer_cls):
             opt = dtt_amd.ClipAdamW([{"params": decay, "weight_decay": 1e-5},
                                      {"params": no_decay, "weight_decay": 0.0}], lr=1e-4, max_norm=2.0)
     return dict(cfg=cfg, B=B, L=L, n_fft=n_fft, hop=hop, step=step, opt=opt, mode=mode, model=model,
-                eager_step=eager_step, reducer=reducer)
+                eager_step=eager_step, reducer=reducer, graph_step=gs if step is not eager_step else None)
+
+
+def choose_launch(w, world, dev, backend, n=4):
+    """--graph auto: the faster of (a) replaying the recorded step and (b) issuing it eagerly, on THIS box.  Eager issue
+    runs the weight gradients and the lip encoder on side streams beside the data-gradient chain (ops.wgrad_lane /
+    ops.video_lane: -5 ms of 41 at cfg4), which a HIP-graph replay did not reproduce (same time with and without the
+    forked branches); the replay wins where the host cannot issue ~1500 launches per step fast enough.  Every rank times
+    both (max over ranks) so that all take the same decision."""
+    import torch.distributed as dist
+    if w.get("graph_step") is None:
+        return
+
+    def timed(fn):
+        for i in range(2):
+            fn(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t)
+        return el / n * 1e3
+    tg = timed(w["step"])
+    te = timed(w["eager_step"])
+    w["calibration"] = {"graph_ms": round(tg, 2), "eager_ms": round(te, 2)}
+    if te < 0.98 * tg:
+        w["step"] = w["eager_step"]
+        w["mode"] = (f"eager issue, weight gradients and lip encoder on side streams (calibration on this box: eager "
+                     f"{te:.1f} ms, graph replay {tg:.1f} ms per step)")
+    else:
+        w["graph_step"].rearm()
+        w["mode"] += f" (calibration on this box: graph replay {tg:.1f} ms, eager {te:.1f} ms per step)"
 
 
 def time_workload(w, steps, warmup, world, dev, backend):
@@ -248,7 +286,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", default="auto", choices=["auto", "0", "1"],
-                    help="record the step into a HIP graph and replay it (auto: fall back to eager if capture fails)")
+                    help="1: record the step into a HIP graph and replay it; 0: issue it eagerly; auto: time both on this box "
+                         "and take the faster (eager if the capture fails)")
     ap.add_argument("--sharded-optimizer", action="store_true",
                     help="N > 1: reduce-scatter -> clip + AdamW on 1/N of the parameters -> all-gather (ShardedClipAdamW) "
                          "instead of bucketed all-reduce + replicated update")
@@ -286,10 +325,13 @@ def main():
     from dtt_amd.dist import GradBucketReducer
 
     w = build_workload(args.workload, args, dev, rank, world, GradBucketReducer)
+    if args.graph == "auto":
+        choose_launch(w, world, dev, backend)
     cfg, B, launch_mode = w["cfg"], w["B"], w["mode"]
     elapsed, enqueue, loss_val = time_workload(w, args.steps, args.warmup, world, dev, backend)
     host_issue_ms = w["host_issue_ms"]
     w_first = w["first_loss"]
+    w_cal = w.get("calibration")
 
     # SURVEY 8(d) wants the optimizer's share stated beside the step: events on the launch stream around a few
     # extra clip+AdamW calls on the last step's gradients (outside the timed region)
@@ -310,6 +352,8 @@ def main():
         del w
         torch.cuda.empty_cache()
         w2 = build_workload("audio15m", args, dev, rank, world, GradBucketReducer)
+        if args.graph == "auto":
+            choose_launch(w2, world, dev, backend)
         el2, enq2, loss2 = time_workload(w2, max(5, args.steps // 2), 3, world, dev, backend)
         n2 = max(5, args.steps // 2)
         also = {"workload": "audio15m: DTTNet audio-only 15M training step, B=64 x 2 s (BASELINE.json configs[1])",
@@ -333,6 +377,7 @@ def main():
             "config": {"workload": f"{args.workload}: {NAMES[cfg['model']]} training step (STFT+fwd+PIT-L1+bwd"
                                    f"+clip+AdamW), B={B}/GPU x {cfg['seconds']:.0f} s, n_fft 1024 hop 256",
                        "global_batch": B * world, "parallelism": f"dp{world}", "launch": launch_mode,
+                       "launch_calibration_ms_per_step": w_cal,
                        "first_loss": None if w_first is None else round(w_first, 4), "final_loss": round(loss_val, 4),
                        "host_issue_ms_per_step": round(host_issue_ms, 2),
                        "host_enqueue_ms_per_step_back_to_back": round(enqueue / args.steps * 1e3, 2),
@@ -381,16 +426,24 @@ def step_roofline(w, cfg, B, precision, workload):
     launches per step, average duration, algorithmic flops or bytes per launch and fraction of the
     roofline that bounds them; `by_family` sums the step by kernel family.  The same table, all rows, is written by
     tools/step_table.py and tracked under profiles/."""
-    from dtt_amd import prof
+    from dtt_amd import ops, prof
     step = w["eager_step"]
-    for i in range(2):
-        step(i)
-    torch.cuda.synchronize()
-    n = 3
-    with prof.CallTimer() as ct:
-        for i in range(n):
+    # one stream for the table: beside another kernel an entry's bracket measures the pair, not the entry
+    lanes = (ops._WGRAD_LANE[0], ops._VIDEO_LANE[0])
+    ops.wgrad_lane(False)
+    ops.video_lane(False)
+    try:
+        for i in range(2):
             step(i)
-    tab = ct.table(n)
+        torch.cuda.synchronize()
+        n = 3
+        with prof.CallTimer() as ct:
+            for i in range(n):
+                step(i)
+        tab = ct.table(n)
+    finally:
+        ops.wgrad_lane(lanes[0])
+        ops.video_lane(lanes[1])
     rows = tab["rows"]
     for r in rows:
         r["share_of_step"] = round(r["ms_per_step"] / tab["span_ms_per_step"], 4)
@@ -413,8 +466,8 @@ def step_roofline(w, cfg, B, precision, workload):
         head["traffic"] = _tracked_traffic(_traffic_key(head)) if precision == "bf16" and B == cfg["batch"] else None
     for r in top:
         r["traffic"] = _tracked_traffic(_traffic_key(r)) if precision == "bf16" and B == cfg["batch"] else None
-    head["measured"] = (f"{n} eager steps of {workload} with HIP events around every C-ABI call on the launch stream "
-                        f"(dtt_amd/prof.py); eager step {tab['span_ms_per_step']:.2f} ms, of which {tab['entry_points_ms_per_step']:.2f} ms "
+    head["measured"] = (f"{n} eager steps of {workload} on ONE stream (side streams off) with HIP events around every C-ABI "
+                        f"call on the launch stream (dtt_amd/prof.py); eager step {tab['span_ms_per_step']:.2f} ms, of which {tab['entry_points_ms_per_step']:.2f} ms "
                         f"inside entry points")
     head["top"] = top
     head["by_family_ms_per_step"] = fam

@@ -140,6 +140,9 @@ class GradBucketReducer:
 
     def _launch(self, bi):
         flat, ps, views = self.buckets[bi]
+        if flat.is_cuda:
+            from . import ops
+            ops.join_wgrad_lane()                         # the gradients about to be copied may still be on the side stream
         have = [(v, p.grad) for v, p in zip(views, ps) if p.grad is not None]
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
@@ -336,6 +339,9 @@ class ShardedClipAdamW:
     @torch.no_grad()
     def step(self):
         """Returns the global (unclipped) gradient norm as a 1-element device tensor when max_norm is set."""
+        if self.flat_p.is_cuda:
+            from . import ops
+            ops.join_wgrad_lane()
         have = [(v, p.grad) for v, p in zip(self.gviews, self.params) if p.grad is not None]
         missing = [v for v, p in zip(self.gviews, self.params) if p.grad is None]
         if have:

@@ -168,8 +168,18 @@ class GraphedTrainStep:
         batch.update(self.model(**batch))
         batch.update(self.criterion(**batch))
         batch["loss"].backward()
+        ops.join_wgrad_lane()                              # (the backward pass joined its side stream already)
         ops.join_packs()
         return batch["loss"]
+
+    def rearm(self):
+        """After EAGER steps on the same model and optimizer (which left their own gradient tensors in ``.grad`` and
+        their addresses in the optimizer's tables): point both back at the graph's static gradients."""
+        for p, g in zip(self.params, self.graph_grads):
+            p.grad = g
+        if (self.world == 1 or self.overlap) and hasattr(self.opt, "note_gradients"):
+            by_param = {id(p): g for p, g in zip(self.params, self.graph_grads)}
+            self.opt.note_gradients([by_param.get(id(p)) for p in self.opt._built["params"]])
 
     def _eager_once(self, step_opt):
         for p in self.params:

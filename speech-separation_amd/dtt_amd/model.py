@@ -343,11 +343,16 @@ class DTTNetVisionModel(_SeparatorBase):
     def forward(self, spectrogram, video, phase, audio_length, video_features=None, **batch):
         self._check(spectrogram)
         ops.prepare_packs()
-        x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
         if video_features is None:                      # (tests may feed encoder outputs directly)
-            video_features = self.encode_video(video)
+            # the lip encoder on a stream of its own, beside the audio encoder (ops.video_lane)
+            with ops.video_stream(spectrogram.device) as vs:
+                video_features = self.encode_video(video)
+            x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
+            video_features = vs.join(video_features)
             if _Tap.store is not None:
                 _Tap.store["video_encoder"] = video_features.detach().float()
+        else:
+            x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
         x = self.fusion(x, video_features)
         _Tap.put("fusion", x)
         x = self.latent(x)
@@ -381,11 +386,16 @@ class DTTNetPlusModel(_SeparatorBase):
         post_processor) or ``video_encoded`` [B,T_v,D] (behind it)."""
         self._check(spectrogram)
         ops.prepare_packs()
-        x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
-        if video_encoded is None:
-            if video_features is None:
+        if video_encoded is None and video_features is None:
+            # the frozen lip front end on a stream of its own, beside the audio encoder (ops.video_lane)
+            with ops.video_stream(spectrogram.device) as vs:
                 video_features = self.video_encoder.features(video, self.compute_dtype() == torch.bfloat16)
-            elif video_features.dim() != 3 or video_features.shape[-1] != 2048:
+            x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
+            video_features = vs.join(video_features)
+        else:
+            x, skips = self.encoder(spectrogram, phase, self.compute_dtype())
+        if video_encoded is None:
+            if video_features.dim() != 3 or video_features.shape[-1] != 2048:
                 raise DttError("video_features must be [B, T_v, 2048]")
             with torch.autocast("cuda", enabled=False):
                 pp = self.video_encoder.post_processor          # trainable Linear(2048 -> D), fp32, through dtt_gemm

@@ -58,6 +58,113 @@ def reset_zero_arena():
 
 
 # --------------------------------------------------------------------------- #
+# Weight gradients on a second stream
+# --------------------------------------------------------------------------- #
+class _Lane:
+    def __init__(self):
+        self.stream, self.pending, self.keep, self.cb = None, False, [], False
+
+
+_LANES = {}
+_WGRAD_LANE = [os.environ.get("DTT_WGRAD_LANE", "1") == "1"]
+
+
+def wgrad_lane(enabled=True):
+    """Weight-gradient kernels (conv / Linear / LSTM weight and bias gradients: ~7 ms of a 40 ms cfg4 step) depend on
+    nothing downstream but the optimizer, while the data-gradient chain they sit in is a string of launches that do not
+    fill the chip at B = 16.  With the lane enabled each backward forks them onto a second stream (an event wait each
+    way; under a HIP-graph capture: a parallel branch of the graph) and joins at the end of the backward pass
+    (autograd's final callback), so they run beside the data-gradient kernels.  The tensors they read are kept alive
+    until the join; their outputs are allocated on the launch stream before the fork.  Consumers of .grad that run
+    INSIDE the backward pass (gradient accumulation into an existing .grad, post-accumulate hooks) must call
+    join_wgrad_lane() first: GradBucketReducer's hooks do."""
+    _WGRAD_LANE[0] = bool(enabled)
+
+
+class _lane:
+    """with _lane(dev, tensors to keep alive...): launches inside go to the device's side stream."""
+
+    def __init__(self, dev, *keep):
+        self.dev, self.keep, self.ctx = dev, keep, None
+
+    def __enter__(self):
+        if not _WGRAD_LANE[0] or self.dev.type != "cuda":
+            return self
+        ln = _LANES.setdefault(_dev_index(self.dev), _Lane())
+        if ln.stream is None:
+            ln.stream = torch.cuda.Stream(self.dev)
+        ln.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        ln.keep.extend(self.keep)
+        ln.pending = True
+        if not ln.cb:
+            try:                                   # joined when the backward pass that issued the work ends
+                torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_lane)
+                ln.cb = True
+            except RuntimeError:                   # not inside a backward pass: the caller joins
+                pass
+        self.ctx = torch.cuda.stream(ln.stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_wgrad_lane():
+    """The launch stream waits for every weight-gradient launch issued so far (no host sync)."""
+    for idx, ln in _LANES.items():
+        if ln.pending:
+            torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(ln.stream)
+            ln.keep.clear()
+            ln.pending = False
+        ln.cb = False
+
+
+_VIDEO_LANE = [os.environ.get("DTT_VIDEO_LANE", "1") == "1"]
+_VIDEO_STREAMS = {}
+
+
+def video_lane(enabled=True):
+    """The lip encoder's forward depends on nothing but the clip, and its backward on nothing but the fusion's gradient:
+    with the lane enabled the models run it on a stream of its own beside the audio encoder (autograd runs a node's
+    backward on the stream of its forward and orders the streams where gradients cross).  Not used while a HIP graph
+    is being captured (the graphed step keeps one branch)."""
+    _VIDEO_LANE[0] = bool(enabled)
+
+
+class video_stream:
+    """with video_stream(dev) as vs: y = lip_encoder(...)   then   y = vs.join(y) on the launch stream."""
+
+    def __init__(self, dev):
+        self.dev, self.st, self.ctx = dev, None, None
+
+    def __enter__(self):
+        if _VIDEO_LANE[0] and self.dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            self.st = _VIDEO_STREAMS.get(_dev_index(self.dev))
+            if self.st is None:
+                self.st = _VIDEO_STREAMS[_dev_index(self.dev)] = torch.cuda.Stream(self.dev)
+            self.st.wait_stream(torch.cuda.current_stream(self.dev))
+            self.ctx = torch.cuda.stream(self.st)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.st is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_stream(self.st)
+            for t in tensors:
+                t.record_stream(cur)                   # allocated on the side stream's pool, consumed on this one
+        return tensors[0] if len(tensors) == 1 else tensors
+
+
+# --------------------------------------------------------------------------- #
 # thin wrappers over the C entry points
 # --------------------------------------------------------------------------- #
 def conv_gemm(x, wp, bias, out, geom, res=None, phases=False, res00=None):
@@ -116,9 +223,10 @@ def conv_wgrad(p_side, q_side, geom, M, N):
     dwp = _zeros_f32((M, 9, N,), p_side.device)
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * 9
     splitk = int(max(1, min(512, round(768 / tiles), (P + 255) // 256)))     # ~3 workgroups per CU: atomic tail
-    gemm_raw(A=p_side, B=q_side, C=dwp, M=M, N=N, K=P, batch=9, splitk=splitk, a_ms=1, a_ks=M, a_bs=0,
-             b_ks=N, b_ns=1, b_bs=0, c_ms=9 * N, c_ns=1, c_bs=N, dtype=_dt(p_side), atomic=1, out_f32=1,
-             b_mode=1, **geom)
+    with _lane(p_side.device, p_side, q_side):
+        gemm_raw(A=p_side, B=q_side, C=dwp, M=M, N=N, K=P, batch=9, splitk=splitk, a_ms=1, a_ks=M, a_bs=0,
+                 b_ks=N, b_ns=1, b_bs=0, c_ms=9 * N, c_ns=1, c_bs=N, dtype=_dt(p_side), atomic=1, out_f32=1,
+                 b_mode=1, **geom)
     return dwp
 
 
@@ -489,18 +597,21 @@ def _conv_backward(kind, x, w, dy, need_dx, tile=True, phases=False, res=None, r
             need = lib().dtt_conv3x3_wgrad_ws_bytes(B, Fi, Ti, Ci, Co)
             if need > 0:        # partial sums through a workspace + one sum launch instead of fp32 atomics;
                 dw = _empty((Co, Ci, 3, 3), F32, x.device)      # the sum writes the parameter's own layout
-                ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-                check(lib().dtt_conv3x3_wgrad_ws_param(ptr(dy), ptr(x), ptr(dw), ptr(ws), C.c_int64(need), B, Fi, Ti, Ci,
-                                                       Co, 1, stream_ptr()), "dtt_conv3x3_wgrad_ws_param")
+                with _lane(x.device, dy, x):
+                    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+                    check(lib().dtt_conv3x3_wgrad_ws_param(ptr(dy), ptr(x), ptr(dw), ptr(ws), C.c_int64(need), B, Fi, Ti,
+                                                           Ci, Co, 1, stream_ptr()), "dtt_conv3x3_wgrad_ws_param")
                 dx = conv3x3_s1(dy, _pack_dgrad(w, kind, x.dtype), None, res=res)[0] if need_dx else None
                 return dx, dw
             else:
                 dwp = _zeros_f32((Co, 9, Ci,), x.device)
-                check(lib().dtt_conv3x3_wgrad(ptr(dy), ptr(x), ptr(dwp), B, Fi, Ti, Ci, Co, 1, stream_ptr()),
-                      "dtt_conv3x3_wgrad")
+                with _lane(x.device, dy, x):
+                    check(lib().dtt_conv3x3_wgrad(ptr(dy), ptr(x), ptr(dwp), B, Fi, Ti, Ci, Co, 1, stream_ptr()),
+                          "dtt_conv3x3_wgrad")
         else:
             dwp = conv_wgrad(dy, x, gw, Co, Ci)
-        dw = dwp.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
+        with _lane(x.device, dwp):
+            dw = dwp.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
         dx = conv3x3_s1(dy, _pack_dgrad(w, kind, x.dtype), None, res=res)[0] if need_dx else None
         return dx, dw
     if kind == "up":
@@ -509,11 +620,13 @@ def _conv_backward(kind, x, w, dy, need_dx, tile=True, phases=False, res=None, r
     else:
         dwp = conv_wgrad(dy, x, gw, Co, Ci)                      # [Co][9][Ci]
         dw = dwp.view(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+    with _lane(x.device, dwp):
+        dw = dw.contiguous()
     dx = None
     if need_dx:
         dx = torch.empty_like(x)
         conv_gemm(dy, _pack_dgrad(w, kind, x.dtype), None, dx, gd, phases=phases, res=res, res00=res00)
-    return dx, dw.contiguous()
+    return dx, dw
 
 
 class ConvNormGelu(torch.autograd.Function):
@@ -572,7 +685,8 @@ class ConvAdd(torch.autograd.Function):
         dy = dy.contiguous()
         dx, dw = _conv_backward("s1", x, w, dy, ctx.needs_input_grad[0])
         Co = dy.shape[3]
-        db = colsum(dy, dy.numel() // Co, Co)
+        with _lane(dy.device, dy):
+            db = colsum(dy, dy.numel() // Co, Co)
         if ctx.slot is not None and dx is not None:
             ctx.slot.put(dx)                 # x's other consumer (conv1[0]) adds it inside its data-gradient conv
             dx = None
@@ -673,8 +787,9 @@ class Conv1x1s2(torch.autograd.Function):
             dyc = dyc.contiguous()
         P = B * g["cFo"] * g["cTo"]
         dwp = _zeros_f32((Co, Ci), xc.device)
-        gemm_raw(A=dyc, B=xc, C=dwp, M=Co, N=Ci, K=P, splitk=_splitk(Co, Ci, P), a_ms=1, a_ks=Co, b_ks=Ci, b_ns=1, c_ms=Ci,
-                 c_ns=1, dtype=_dt(xc), atomic=1, out_f32=1, b_mode=1, **g)
+        with _lane(xc.device, dyc, xc):
+            gemm_raw(A=dyc, B=xc, C=dwp, M=Co, N=Ci, K=P, splitk=_splitk(Co, Ci, P), a_ms=1, a_ks=Co, b_ks=Ci, b_ns=1, c_ms=Ci,
+                     c_ns=1, dtype=_dt(xc), atomic=1, out_f32=1, b_mode=1, **g)
         dx = None
         if ctx.needs_input_grad[0]:
             t = _empty((P, Ci), xc.dtype, xc.device)
@@ -735,9 +850,10 @@ class FrontConv(torch.autograd.Function):
         P, N = g["cB"] * g["cFo"] * g["cTo"], KH * 64
         dwp = _zeros_f32((Co, N), dy.device)
         tiles = -(-Co // 64) * -(-N // 128)
-        gemm_raw(A=dy, B=x5p, C=dwp, M=Co, N=N, K=P, splitk=max(1, min(256, 512 // tiles)), a_ms=1, a_ks=Co, b_ks=N, b_ns=1,
-                 c_ms=N, c_ns=1, dtype=_dt(dy), atomic=1, out_f32=1, b_mode=1, **g)
-        dw = dwp.view(Co, KH, 8, 8)[:, :, :KWr, :kt].permute(0, 3, 1, 2).unsqueeze(1).contiguous()
+        with _lane(dy.device, dy, x5p, dwp):
+            gemm_raw(A=dy, B=x5p, C=dwp, M=Co, N=N, K=P, splitk=max(1, min(256, 512 // tiles)), a_ms=1, a_ks=Co, b_ks=N,
+                     b_ns=1, c_ms=N, c_ns=1, dtype=_dt(dy), atomic=1, out_f32=1, b_mode=1, **g)
+            dw = dwp.view(Co, KH, 8, 8)[:, :, :KWr, :kt].permute(0, 3, 1, 2).unsqueeze(1).contiguous()
         return None, dw, None, None
 
 
@@ -781,21 +897,19 @@ class TDF(torch.autograd.Function):
         gemm_raw(A=w2p, B=dout, C=dhid, M=J, N=N, K=Fq, batch=B, a_ms=1, a_ks=J, a_bs=0, b_ks=N, b_ns=1,
                  b_bs=Fq * N, c_ms=N, c_ns=1, c_bs=J * N, dtype=d)
         dx = torch.empty_like(x)
+        dw2, dw1, db2, db1 = _zeros_f32((Fq, J,), dev), _zeros_f32((J, Fq,), dev), _zeros_f32((Fq,), dev), _zeros_f32((J,), dev)
+        ones = torch.ones(N, dtype=x.dtype, device=dev)
+        with _lane(dev, dout, hid, dhid, x, ones):
+            gemm_raw(A=dout, B=hid, C=dw2, M=Fq, N=J, K=N, batch=B, splitk=_splitk(Fq, J, N, B), a_ms=N, a_ks=1, a_bs=Fq * N,
+                     b_ks=1, b_ns=N, b_bs=J * N, c_ms=J, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
+            gemm_raw(A=dhid, B=x, C=dw1, M=J, N=Fq, K=N, batch=B, splitk=_splitk(J, Fq, N, B), a_ms=N, a_ks=1, a_bs=J * N,
+                     b_ks=1, b_ns=N, b_bs=Fq * N, c_ms=Fq, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
+            gemm_raw(A=dout, B=ones, C=db2, M=Fq, N=1, K=N, batch=B, a_ms=N, a_ks=1, a_bs=Fq * N, b_ks=1, b_ns=0,
+                     b_bs=0, c_ms=1, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
+            gemm_raw(A=dhid, B=ones, C=db1, M=J, N=1, K=N, batch=B, a_ms=N, a_ks=1, a_bs=J * N, b_ks=1, b_ns=0,
+                     b_bs=0, c_ms=1, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
         gemm_raw(A=w1p, B=dhid, C=dx, R=dout, M=Fq, N=N, K=J, batch=B, a_ms=1, a_ks=Fp, a_bs=0, b_ks=N, b_ns=1,
                  b_bs=J * N, c_ms=N, c_ns=1, c_bs=Fq * N, r_ms=N, r_ns=1, r_bs=Fq * N, dtype=d)
-        dw2 = _zeros_f32((Fq, J,), dev)
-        gemm_raw(A=dout, B=hid, C=dw2, M=Fq, N=J, K=N, batch=B, splitk=_splitk(Fq, J, N, B), a_ms=N, a_ks=1, a_bs=Fq * N, b_ks=1,
-                 b_ns=N, b_bs=J * N, c_ms=J, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
-        dw1 = _zeros_f32((J, Fq,), dev)
-        gemm_raw(A=dhid, B=x, C=dw1, M=J, N=Fq, K=N, batch=B, splitk=_splitk(J, Fq, N, B), a_ms=N, a_ks=1, a_bs=J * N, b_ks=1,
-                 b_ns=N, b_bs=Fq * N, c_ms=Fq, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
-        ones = torch.ones(N, dtype=x.dtype, device=dev)
-        db2 = _zeros_f32((Fq,), dev)
-        gemm_raw(A=dout, B=ones, C=db2, M=Fq, N=1, K=N, batch=B, a_ms=N, a_ks=1, a_bs=Fq * N, b_ks=1, b_ns=0,
-                 b_bs=0, c_ms=1, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
-        db1 = _zeros_f32((J,), dev)
-        gemm_raw(A=dhid, B=ones, C=db1, M=J, N=1, K=N, batch=B, a_ms=N, a_ks=1, a_bs=J * N, b_ks=1, b_ns=0,
-                 b_bs=0, c_ms=1, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
         return dx, dw1, db1, dw2, db2
 
 
@@ -1101,9 +1215,10 @@ class DualPathRNN(torch.autograd.Function):
         gemm_raw(A=dout, B=fcw, C=dy, M=R, N=2 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=2 * H, b_ns=1, c_ms=2 * H, c_ns=1,
                  dtype=d)
         dfcw = _zeros_f32((Cp, 2 * H,), dev)
-        gemm_raw(A=dout, B=y, C=dfcw, M=Cp, N=2 * H, K=R, splitk=_splitk(Cp, 2 * H, R), a_ms=1, a_ks=Cp, b_ks=2 * H, b_ns=1,
-                 c_ms=2 * H, c_ns=1, dtype=d, atomic=1, out_f32=1)
-        dfcb = colsum(dout, R, Cp)
+        with _lane(dev, dout, y):
+            gemm_raw(A=dout, B=y, C=dfcw, M=Cp, N=2 * H, K=R, splitk=_splitk(Cp, 2 * H, R), a_ms=1, a_ks=Cp, b_ks=2 * H,
+                     b_ns=1, c_ms=2 * H, c_ns=1, dtype=d, atomic=1, out_f32=1)
+            dfcb = colsum(dout, R, Cp)
         # recurrent backward
         dG = _empty((R, 2, 4 * H), dt, dev)
         dbias = None
@@ -1139,17 +1254,16 @@ class DualPathRNN(torch.autograd.Function):
             check(lib().dtt_lstm_bwd(ptr(dy), ptr(gates), ptr(cst), ptr(wpt), ptr(dG), nslab * heads, L, heads, H, d,
                                      stream_ptr()), "dtt_lstm_bwd")
         G4 = 4 * H
-        dwhh = []
-        for di, (shift, edge) in enumerate(((-heads, 0), (heads, L - 1))):
-            g = _zeros_f32((G4, H,), dev)
-            gemm_raw(A=dG[:, di], B=y[:, di * H:], C=g, M=G4, N=H, K=R, splitk=_splitk(G4, H, R), a_ms=1, a_ks=2 * G4, b_ks=2 * H,
-                     b_ns=1, c_ms=H, c_ns=1, dtype=d, atomic=1, out_f32=1, b_mode=2, sh_shift=shift,
-                     sh_heads=heads, sh_L=L, sh_edge=edge)
-            dwhh.append(g)
+        dwhh = [_zeros_f32((G4, H,), dev), _zeros_f32((G4, H,), dev)]
         dwih = _zeros_f32((2 * G4, Cp,), dev)
-        gemm_raw(A=dG, B=xn, C=dwih, M=2 * G4, N=Cp, K=R, splitk=_splitk(2 * G4, Cp, R), a_ms=1, a_ks=2 * G4, b_ks=Cp, b_ns=1,
-                 c_ms=Cp, c_ns=1, dtype=d, atomic=1, out_f32=1)
-        if dbias is None:
+        with _lane(dev, dG, y, xn):
+            for di, (shift, edge) in enumerate(((-heads, 0), (heads, L - 1))):
+                gemm_raw(A=dG[:, di], B=y[:, di * H:], C=dwhh[di], M=G4, N=H, K=R, splitk=_splitk(G4, H, R), a_ms=1, a_ks=2 * G4,
+                         b_ks=2 * H, b_ns=1, c_ms=H, c_ns=1, dtype=d, atomic=1, out_f32=1, b_mode=2, sh_shift=shift,
+                         sh_heads=heads, sh_L=L, sh_edge=edge)
+            gemm_raw(A=dG, B=xn, C=dwih, M=2 * G4, N=Cp, K=R, splitk=_splitk(2 * G4, Cp, R), a_ms=1, a_ks=2 * G4, b_ks=Cp,
+                     b_ns=1, c_ms=Cp, c_ns=1, dtype=d, atomic=1, out_f32=1)
+        if dbias is None:           # (on the launch stream: each half is returned for two parameters, which autograd clones)
             dbias = colsum(dG, R, 2 * G4)
         dxn = _empty((nslab, L, Cc), dt, dev)
         gemm_raw(A=dG, B=wih, C=dxn, M=R, N=Cp, K=2 * G4, a_ms=2 * G4, a_ks=1, b_ks=Cp, b_ns=1, c_ms=Cp, c_ns=1,
@@ -1438,8 +1552,9 @@ def _linear_bwd(x2d, w, dy2d, need_dx=True):
         dx = torch.empty_like(x2d)
         gemm_raw(A=dy2d, B=w, C=dx, M=R, N=K, K=N, a_ms=N, a_ks=1, b_ks=K, b_ns=1, c_ms=K, c_ns=1, dtype=d)
     dw = _zeros_f32((N, K,), x2d.device)
-    gemm_raw(A=dy2d, B=x2d, C=dw, M=N, N=K, K=R, splitk=_splitk(N, K, R), a_ms=1, a_ks=N, b_ks=K,
-             b_ns=1, c_ms=K, c_ns=1, dtype=d, atomic=1, out_f32=1)
+    with _lane(x2d.device, dy2d, x2d):
+        gemm_raw(A=dy2d, B=x2d, C=dw, M=N, N=K, K=R, splitk=_splitk(N, K, R), a_ms=1, a_ks=N, b_ks=K,
+                 b_ns=1, c_ms=K, c_ns=1, dtype=d, atomic=1, out_f32=1)
     return dx, dw
 
 

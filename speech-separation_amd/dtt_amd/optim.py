@@ -138,6 +138,7 @@ class ClipAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         from . import ops
+        ops.join_wgrad_lane()                                 # (a no-op after a complete backward pass: it joins itself)
         ops.handoff_poll()                                    # hand-off LSTM kernels of this backward (non-blocking)
         b = self._built
         if b is None or [p.data_ptr() for p in b["params"]] != b["ptrs"]:
@@ -204,6 +205,16 @@ class ClipAdamW(torch.optim.Optimizer):
         if not self.capturable or self._built is None:
             raise DttError("refresh_hyper() is for a capturable ClipAdamW whose step() has been recorded")
         self._upload()
+
+    def note_gradients(self, grads):
+        """capturable mode: the gradient tensors the recorded step() reads (one per parameter, None allowed).  A graph
+        owner calls this after eager step() calls on the same optimizer, which noted their own gradients' addresses."""
+        b = self._built
+        if b is None:
+            raise DttError("note_gradients() before the optimizer was built")
+        gptrs = [0 if g is None else g.data_ptr() for g in grads]
+        for t in b["tabs"]:
+            t["g"] = gptrs
 
     def note_recorded_step(self):
         """Undo the host-side count of a step() that was only recorded into a graph (recording executes nothing)."""

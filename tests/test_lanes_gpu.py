@@ -1,0 +1,147 @@
+"""Side streams of the eagerly issued step (ops.wgrad_lane: weight gradients beside the data-gradient chain;
+ops.video_lane: the lip encoder beside the audio encoder): same losses, gradients and updated parameters as the
+one-stream step, step after step (the joins order every consumer), and a graph owner can hand the optimizer back its
+static gradients after eager steps (GraphedTrainStep.rearm).  Reference step: src/trainer/trainer.py:37-72."""
+import copy
+
+import pytest
+import torch
+
+from oracle.fill import synth_video
+from helpers import grad_close, make_batch, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(seed, precision):
+    import dtt_amd
+    torch.manual_seed(seed)
+    return dtt_amd.DTTNetVisionModel(g=8, n_sources=2, n_layers=3, n_idp_layers=1, n_fft=64, hop_length=16, n_heads=2,
+                                     video_channels=512, fusion_method="cross_attention_positional",
+                                     precision=precision).to(DEV)
+
+
+def _steps(model, lanes, nsteps, precision):
+    import dtt_amd
+    from dtt_amd import ops
+    keep = (ops._WGRAD_LANE[0], ops._VIDEO_LANE[0])
+    ops.wgrad_lane(lanes)
+    ops.video_lane(lanes)
+    try:
+        model.train()
+        opt = dtt_amd.ClipAdamW(model.parameters(), lr=1e-3, max_norm=2.0)
+        crit = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())
+        video = synth_video(2, 4, seed=77).to(DEV)
+        losses, grads = [], None
+        for i in range(nsteps):
+            b = to_dev(make_batch(2, 800, 64, 16, seed=50 + i), DEV)
+            for p in model.parameters():
+                p.grad = None
+            b.update(model(video=video, **b))
+            b.update(crit(**b))
+            b["loss"].backward()
+            if i == 0:                     # before any update: later steps inherit the run-to-run noise of the atomics
+                grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            opt.step()
+            losses.append(float(b["loss"].detach()))
+        torch.cuda.synchronize()
+        return losses, grads, {n: p.detach().clone() for n, p in model.named_parameters()}
+    finally:
+        ops.wgrad_lane(keep[0])
+        ops.video_lane(keep[1])
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
+def test_side_streams_change_nothing_but_the_schedule(precision, tol):
+    base = _model(3, precision)
+    other = copy.deepcopy(base)
+    again = copy.deepcopy(base)
+    l0, g0, p0 = _steps(base, False, 3, precision)
+    l1, g1, p1 = _steps(other, True, 3, precision)
+    l2, g2, p2 = _steps(again, False, 3, precision)        # the one-stream step against itself: the noise floor
+    # split-K weight gradients add their partial sums with fp32 atomics (order varies run to run): close, not identical
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= tol * abs(a), (l0, l1)
+    assert set(g0) == set(g1) and len(g0) > 100
+    # (grad_close: gradients that are mathematically zero -- a bias ahead of a normalisation -- hold rounding noise only)
+    atol = 2e-6 if precision == "fp32" else 2e-3
+    bad = [k for k in g0 if not grad_close(g1[k], g0[k], max(10 * tol, 20 * rel_err(g2[k], g0[k])), atol=atol)]
+    assert not bad, [(k, rel_err(g1[k], g0[k]), rel_err(g2[k], g0[k]), float(g0[k].abs().max())) for k in bad[:5]]
+    for k in p0:                                           # three updates later: within a few times the noise floor
+        e, floor = rel_err(p1[k], p0[k]), rel_err(p2[k], p0[k])
+        assert e < max(tol, 20 * floor), (k, e, floor)
+
+
+def test_side_streams_survive_a_consumer_inside_backward():
+    """A post-accumulate hook reads .grad while the backward pass is still running: after join_wgrad_lane() (what
+    GradBucketReducer's bucket launch calls) the value is final."""
+    from dtt_amd import ops
+    import dtt_amd
+    model = _model(4, "fp32")
+    seen = {}
+
+    def hook(p):
+        ops.join_wgrad_lane()
+        seen[id(p)] = p.grad.detach().clone()
+    hs = [p.register_post_accumulate_grad_hook(hook) for p in model.parameters() if p.requires_grad]
+    crit = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())
+    b = to_dev(make_batch(2, 800, 64, 16, seed=60), DEV)
+    b.update(model(video=synth_video(2, 4, seed=78).to(DEV), **b))
+    b.update(crit(**b))
+    b["loss"].backward()
+    torch.cuda.synchronize()
+    for h in hs:
+        h.remove()
+    n = 0
+    for p in model.parameters():
+        if p.grad is not None:
+            assert torch.equal(seen[id(p)], p.grad)
+            n += 1
+    assert n > 100
+
+
+def test_graph_step_rearms_after_eager_steps():
+    """bench.py --graph auto times eager steps between graph replays: rearm() must hand the recorded optimizer step its
+    static gradients back, or every other replay would update from a stale eager gradient."""
+    import dtt_amd
+    from dtt_amd import ops
+    from oracle.fill import synth_sources
+    from test_graph_gpu import _setup, _batch_fn
+    pool = []
+    for i in range(2):
+        s1, s2 = synth_sources(2, 800, seed=80 + i)
+        pool.append({"s1": s1.to(DEV), "s2": s2.to(DEV)})
+
+    def run(with_graph):
+        m, opt, crit = _setup(with_graph)
+
+        def eager(i):
+            b = _batch_fn(pool[i % 2])
+            for p in m.parameters():
+                p.grad = None
+            b.update(m(**b))
+            b.update(crit(**b))
+            b["loss"].backward()
+            opt.step()
+            return float(b["loss"].detach())
+        if not with_graph:
+            return [eager(i) for i in range(6)]
+        gs = dtt_amd.GraphedTrainStep(m, crit, opt, pool[0], _batch_fn, warmup=1)
+        out = [float(gs(pool[0])), float(gs(pool[1]))]
+        out += [eager(0), eager(1)]
+        gs.rearm()
+        for i in range(2):                                        # two replays: the optimizer alternates two tables
+            out.append(float(gs(pool[i])))
+            seen = float(opt._built["norm"])                      # the norm the recorded clip + AdamW computed ...
+            have = float(torch.sqrt(sum((g.double() ** 2).sum() for g in gs.graph_grads if g is not None)))
+            assert abs(seen - have) < 1e-4 * have, (i, seen, have)    # ... is the norm of the graph's own gradients
+        return out
+    try:
+        want = run(False)
+        got = run(True)
+    finally:
+        ops.reset_zero_arena()
+    assert want[0] > want[-1]                                    # the steps train
+    for i, (a, b) in enumerate(zip(got, want)):                  # (later steps drift like any two runs: test_graph_gpu.py)
+        assert abs(a - b) < (1e-5 if i < 2 else 2e-2) * abs(b), (got, want)

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""FETCH_SIZE / WRITE_SIZE passes of tools/pmc_step.py -> profiles/r03_pmc_traffic.{json,txt}: HBM bytes per launch of
+the step's largest entry points, counted inside the step (every dispatch between an entry's marker and the end marker).
+    python3 tools/pmc_step_parse.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [keys.json]
+Counter unit: KB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies the 128-byte requests of
+16-byte-per-lane streaming reads at 64 bytes -> doubled; WRITE_SIZE is taken as it is."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def by_marker(d, counter):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    disp = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = int(r["Dispatch_Id"])
+        e = disp.setdefault(k, [r["Kernel_Name"], int(r.get("Grid_Size", 0) or 0), 0.0])
+        e[2] += float(r["Counter_Value"])
+    out, calls, cur = collections.defaultdict(float), collections.defaultdict(int), 0
+    for k in sorted(disp):
+        name, grid, v = disp[k]
+        if "binary_kernel<float, 0>" in name and grid <= 64 * 256:
+            cur = grid // 256 - 1
+            if cur > 0:
+                calls[cur] += 1
+            continue
+        if cur > 0:
+            out[cur] += v
+    return out, calls
+
+
+def main():
+    keys = json.load(open(sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "pmc_step_keys.json")))
+    rd, nrd = by_marker(sys.argv[1], "FETCH_SIZE")
+    wr, nwr = by_marker(sys.argv[2], "WRITE_SIZE")
+    res, lines = {}, []
+    for key, e in keys.items():
+        m = e["marker"]
+        if not nrd.get(m) or not nwr.get(m):
+            continue
+        r = rd[m] / nrd[m] * 1024 * 2
+        w = wr[m] / nwr[m] * 1024
+        res[key] = dict(entry=e["entry"], shape=e["shape"], fetch_bytes_x2=r, write_bytes=w, hbm_bytes_per_launch=r + w,
+                        launches=nrd[m], algorithmic_bytes=e.get("algorithmic_bytes"))
+        alg = f"{e['algorithmic_bytes'] / 1e6:8.1f} MB algorithmic" if e.get("algorithmic_bytes") else "(priced by flops)"
+        sh = " ".join(f"{k}={v}" for k, v in e["shape"].items())
+        lines.append(f"{e['entry'][4:]:24s} read {r / 1e6:8.1f} MB (FETCH_SIZE x2)  written {w / 1e6:8.1f} MB  total {(r + w) / 1e6:8.1f} MB  "
+                     f"{alg}  ({nrd[m]} launches in the step)  {sh}")
+    with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.txt"), "w") as f:
+        f.write(__doc__ + "\n" + "\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

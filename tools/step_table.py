@@ -22,6 +22,9 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--batch", type=int, default=None)
 a = ap.parse_args()
 args = argparse.Namespace(batch=a.batch, precision="bf16", graph="0")
+from dtt_amd import ops  # noqa: E402
+ops.wgrad_lane(False)          # one stream: beside another kernel an entry's bracket would measure the pair
+ops.video_lane(False)
 w = bench.build_workload(a.workload, args, torch.device("cuda", 0), 0, 1, GradBucketReducer)
 for i in range(3):
     w["step"](i)

@@ -39,7 +39,16 @@ def check(rc, what):
         raise DttError(f"{what} failed ({rc}): {lib().dtt_last_error().decode()}")
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """The current stream of the current device as a hipStream_t.  Through torch's raw getters where they exist:
+    torch.cuda.current_stream() builds a Stream object and resolves the device index in Python, 13 us a call --
+    2.6 ms of host time per 1400-launch step in each of the forward and the backward thread."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return C.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -8,6 +8,9 @@ timeout -k 10 600 python3 $R/bench.py > $O/bench_line.json 2> $O/bench.err
 echo "bench done"; tail -c 600 $O/bench_line.json; echo
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r03 -- python3 $R/bench.py --no-cpu-baseline --no-also --steps 10 --warmup 5 > $O/bench_under_profiler.json 2> $O/prof.err
 echo "profile done"
+python3 $R/tools/trace_steps.py $O/prof/r03_kernel_trace.csv 3 60 > $O/by_kernel.txt
+python3 $R/tools/trace_overlap.py $O/prof/r03_kernel_trace.csv > $O/overlap.txt
+rm -f $O/prof/r03_kernel_trace.csv
 for wl in xattn60m audio15m film25m; do
   timeout -k 10 400 python3 $R/tools/step_table.py $wl --json $O/step_table_$wl.json > $O/step_table_$wl.txt 2>/dev/null
   head -2 $O/step_table_$wl.txt | tail -1

@@ -398,7 +398,7 @@ int dtt_bn_relu_shuffle(const void* a, int lda, const float* stats_a, const floa
 int dtt_bn_relu_avgpool(const void* y, const float* stats, const float* gamma, const float* beta, float* out, int NF,
                         int S, int C, int dtype, void* stream);
 /* out[b][t][:] = linear interpolation over time of x[b][:][:] (F.interpolate(mode="linear", align_corners=False) on
- * the time axis, the FiLM block's resampling of the video embedding, block_fusion.py:24-28, and temporal_alignment.py:
+ * the time axis, the FiLM block's resampling of the video embedding, block_fusion.py:18-19, and temporal_alignment.py:
  * 19-22): x fp32 [B][Tin][D] -> out fp32 [B][Tout][D]; the backward is the transposed gather (no atomics):
  * dx [B][Tin][D] from dout [B][Tout][D]. */
 int dtt_lerp_time_fwd(const float* x, float* out, int B, int Tin, int Tout, int D, void* stream);

@@ -212,6 +212,8 @@ def choose_launch(w, world, dev, backend, n=4):
         return
 
     def timed(fn):
+        if world > 1:
+            dist.barrier()                     # ranks start together: a collective waits for its slowest peer
         for i in range(2):
             fn(i)
         if world > 1:
@@ -249,6 +251,7 @@ def time_workload(w, steps, warmup, world, dev, backend):
 
     loss = None
     w["first_loss"] = None
+    barrier()
     for i in range(warmup):
         loss = w["step"](i)
         if i == 0:

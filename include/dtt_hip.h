@@ -217,6 +217,11 @@ int dtt_lstm_rs_bwd(const void* dy, const void* gates_blk, const float* cst_blk,
  * dtt_lstm_cluster_* / dtt_lstm_*. */
 int dtt_lstm_rs_covers(int N, int L, int H, int dtype);
 
+/* Polls a hand-off wait of the register- / LDS-stationary LSTM kernels makes before it gives up and raises the status
+ * words (process-wide, ~1 us per poll; 0 restores the default of 2^23 ~ 8 s).  The default rides out rank skew in a
+ * data-parallel job, where a collective that waits for a peer can hold CUs the launch needs; tests set a small value.
+ * No counterpart in the reference (nn.LSTM has no cross-workgroup hand-off). */
+int dtt_lstm_handoff_spin_limit(unsigned polls);
 /* Hand-off health (no counterpart in the reference: nn.LSTM, latent.py:87-92, cannot fail this way).  The
  * dtt_lstm_rs_* and dtt_lstm_cluster_* launches need all their workgroups co-resident (one per CU); a workgroup
  * that waits ~0.5 s for a peer gives up, raises the launch's status word (sync[0] / the tail word) AND a sticky

@@ -24,6 +24,7 @@
 // MFMA accumulator order):  gates [2][NT][L][4][H][2][16] (T),  cst [2][NT][L][H][2][16] (fp32),  NT = ceil(N/32).
 #include <algorithm>
 #include "common.h"
+unsigned dtt_handoff_spin_limit_value();      // lstm_rs.hip: polls per hand-off wait (dtt_lstm_handoff_spin_limit)
 #include "../../include/dtt_hip.h"
 
 namespace {
@@ -40,7 +41,7 @@ template <typename T> __device__ __forceinline__ float tanh_t(float x) {
 }
 
 constexpr unsigned SYNC_STRIDE = 64;          // uints between counters (256 B: one counter per line pair)
-constexpr unsigned SPIN_LIMIT = 1u << 19;     // bounded poll (~ 0.5 s): then raise the status word and stop waiting
+// polls per wait before it raises the status word and stops waiting: LstmCP::spin (dtt_lstm_handoff_spin_limit, lstm_rs.hip)
 constexpr unsigned OOB = 0xfffffff0u;         // buffer offset beyond num_records: loads return 0, stores are dropped
 
 struct LstmCP {
@@ -51,6 +52,7 @@ struct LstmCP {
     float* cst;          // blocked, required (the cell state round-trips through it)
     unsigned* sync;      // [2*S] counters SYNC_STRIDE apart, then one status word; zeroed by the entry point
     int N, L, heads, H, U, G, S, NT, TPG;
+    unsigned spin;
 };
 
 // 16-byte fragment pieces through buffer instructions with sc1 (bypass this CU's L1 / write through)
@@ -88,12 +90,12 @@ static __device__ unsigned g_cluster_timeouts;
 // `dead` (kept by the polling lane): a wait of this workgroup has timed out once -- a workgroup of the launch is not
 // resident or the launch is broken -- so every later wait is skipped and the kernel drains (results are garbage;
 // the status word says so).
-__device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, unsigned* status, bool& dead) {
+__device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, unsigned* status, bool& dead, unsigned spin_limit) {
     if (threadIdx.x == 0 && !dead) {
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) {
+            if (++spins > spin_limit) {
                 __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&g_cluster_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dead = true;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(512) void lstm_cluster_fwd_kernel(LstmCP p) {
             x_offsets(wave, offX);
             x_issue(offX);
         }
-        if (s > 0) wait_counter(cnt, (unsigned)(p.G * s), status, dead);
+        if (s > 0) wait_counter(cnt, (unsigned)(p.G * s), status, dead, p.spin);
         for (int tl = wave; tl < ntile; tl += 8) {
             const int gt = tile0 + tl, n0 = gt * 32;
             // ---- row bookkeeping: A-fragment row (lr), staging-chunk rows (2 / 4 per lane)
@@ -362,6 +364,7 @@ struct LstmCBP {
     float* dbias;        // [2][4H] fp32, zeroed by the caller (may be NULL)
     unsigned* sync;
     int N, L, heads, H, U, G, S, NT, TPG;
+    unsigned spin;
 };
 
 template <typename T, int AB, bool WLDS>
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(512) void lstm_cluster_bwd_kernel(LstmCBP p) {
             prefetch(wave);
             if (first && inreg) load_state(wave);
         }
-        if (!first) wait_counter(cnt, (unsigned)(p.G * (p.L - 1 - s)), status, dead);
+        if (!first) wait_counter(cnt, (unsigned)(p.G * (p.L - 1 - s)), status, dead, p.spin);
         for (int tl = wave; tl < ntile; tl += 8) {
             const int gt = tile0 + tl, n0 = gt * 32;
             const int nA = n0 + lr;
@@ -673,7 +676,7 @@ extern "C" int dtt_lstm_cluster_fwd(const void* xg, const void* whh, void* y, vo
     const int es = dtype ? 2 : 4;
     DTT_CHECK((int64_t)N * L * 2 * 4 * H * es < (1LL << 32) - 64, "dtt_lstm_cluster_fwd: xg exceeds 32-bit byte offsets");
     const int NT = (N + 31) / 32, TPG = (NT + S - 1) / S;
-    LstmCP p{xg, whh, y, gates_blk, cst_blk, sync, N, L, heads, H, U, G, S, NT, TPG};
+    LstmCP p{xg, whh, y, gates_blk, cst_blk, sync, N, L, heads, H, U, G, S, NT, TPG, dtt_handoff_spin_limit_value()};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool wlds = dtype == 1 && cluster_fwd_lds(H, U, es, true) <= LDS_CAP;
     const size_t sm = cluster_fwd_lds(H, U, es, wlds);
@@ -707,7 +710,7 @@ extern "C" int dtt_lstm_cluster_bwd(const void* dy, const void* gates_blk, const
     const int es = dtype ? 2 : 4;
     DTT_CHECK((int64_t)N * L * 2 * 4 * H * es < (1LL << 32) - 64, "dtt_lstm_cluster_bwd: dG exceeds 32-bit byte offsets");
     const int NT = (N + 31) / 32, TPG = (NT + S - 1) / S;
-    LstmCBP p{dy, gates_blk, cst_blk, whhT, dG, dcbuf, dbias, sync, N, L, heads, H, U, G, S, NT, TPG};
+    LstmCBP p{dy, gates_blk, cst_blk, whhT, dG, dcbuf, dbias, sync, N, L, heads, H, U, G, S, NT, TPG, dtt_handoff_spin_limit_value()};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool wlds = dtype == 1 && cluster_bwd_lds(H, U, es, true) <= LDS_CAP;
     const size_t sm = cluster_bwd_lds(H, U, es, wlds);

@@ -30,6 +30,7 @@
 //   gates [2][NT][L][H/4][32 seq][4 gates][4 units] (bf16, 32 B per granule),  cst [2][NT][L][H/4][32 seq][4] (fp32).
 #include <algorithm>
 #include "common.h"
+unsigned dtt_handoff_spin_limit_value();      // defined below (host)
 #include "../../include/dtt_hip.h"
 
 namespace {
@@ -63,7 +64,7 @@ __device__ unsigned long long rs_stamps[128 * 16];
 #endif
 
 constexpr unsigned SYNC_STRIDE = 64;          // uints between counters (256 B)
-constexpr unsigned SPIN_LIMIT = 1u << 19;     // bounded poll
+constexpr unsigned SPIN_LIMIT_DEFAULT = 1u << 23;     // bounded poll: ~8 s (a poll is ~1 us); dtt_lstm_handoff_spin_limit() changes it
 constexpr unsigned OOB = 0xfffffff0u;         // buffer offset beyond num_records: loads return 0, stores are dropped
 
 __device__ __forceinline__ float lo_bf(unsigned w) { return __uint_as_float(w << 16); }
@@ -92,12 +93,12 @@ __device__ __forceinline__ void rs_role(int b, int G, int S, int& dir, int& sg, 
 static __device__ unsigned g_rs_timeouts;
 
 // every wave polls for itself (lane 0), the rest of the wave reconverges behind it
-__device__ __forceinline__ void rs_wait(unsigned* cnt, unsigned target, unsigned* status, bool& dead) {
+__device__ __forceinline__ void rs_wait(unsigned* cnt, unsigned target, unsigned* status, bool& dead, unsigned spin_limit) {
     if ((threadIdx.x & 63) == 0 && !dead) {
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) {
+            if (++spins > spin_limit) {
                 __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&g_rs_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dead = true;
@@ -116,6 +117,7 @@ struct LstmRF {
     float* cst;          // granules, required
     unsigned* sync;      // one status word, then [2*S][TMAX] counters, all SYNC_STRIDE apart; zeroed by the entry point
     int N, L, hshift, S, NT, TMAX;   // heads = 1 << hshift
+    unsigned spin;                   // polls before a wait gives up (status word)
 };
 
 // MT: 32-row weight tiles per wave (8 hidden units each); KS = H / 16 k-steps.  MT * KS = 64: 256 registers of weights.
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rs_fwd_kernel(LstmRF p) {
         bf16* hcur = hbuf + (q & 1) * (32 * LDH);
         bf16* hnext = hbuf + ((q + 1) & 1) * (32 * LDH);
         if (!DEEP && s > 0) {
-            rs_wait(cnt0 + (size_t)tl * SYNC_STRIDE, (unsigned)(G * s), status, dead);
+            rs_wait(cnt0 + (size_t)tl * SYNC_STRIDE, (unsigned)(G * s), status, dead, p.spin);
             issue_h(s, tl);
             commit_h(hcur);
         }
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rs_fwd_kernel(LstmRF p) {
             if (q + 1 < Q && s1 > 0) commit_h(hnext);              // requested one item ago
             STAMP(6);
             if (ahead2) {
-                if (pv < (unsigned)(G * s2)) rs_wait(cnt0 + (size_t)tl2 * SYNC_STRIDE, (unsigned)(G * s2), status, dead);
+                if (pv < (unsigned)(G * s2)) rs_wait(cnt0 + (size_t)tl2 * SYNC_STRIDE, (unsigned)(G * s2), status, dead, p.spin);
                 issue_h(s2, tl2);
             }
             STAMP(7);
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rs_fwd_deep_kernel(LstmRF p) {
                         const int c = a - A_H;
                         if (c == 0) {
                             asm volatile("" : "+v"(pv));           // the counter is looked at HERE, not where it was read
-                            if (v2 && pv < (unsigned)(G * s2)) rs_wait(cnt0 + (size_t)tl2 * SYNC_STRIDE, (unsigned)(G * s2), status, dead);
+                            if (v2 && pv < (unsigned)(G * s2)) rs_wait(cnt0 + (size_t)tl2 * SYNC_STRIDE, (unsigned)(G * s2), status, dead, p.spin);
                         }
                         const int idx = tid + 256 * c, row = idx / CPRH, part = idx - row * CPRH, n = (tile0 + tl2) * 32 + row;
                         const unsigned off = (v2 && n < p.N) ? ((row_base(n, dir ? t2 + 1 : t2 - 1) * 2u + dir) * (unsigned)H + part * 8) * 2u : OOB;
@@ -581,6 +583,7 @@ struct LstmRB {
     float* dbias;        // [2][4H] fp32, zeroed by the caller (may be NULL)
     unsigned* sync;
     int N, L, hshift, S, NT, TMAX;
+    unsigned spin;
 };
 
 __device__ __forceinline__ void mfma16_wa(f32x4_t& acc, const s16x8_t& wa, const s16x8_t& b) {
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rs_bwd_kernel(LstmRB p) {
             // next item's counter, read ahead of its use (no round trip, no drain at the check)
             pv = __hip_atomic_load(cnt0 + (size_t)tl1 * SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (!first) {
-            rs_wait(cnt0 + (size_t)tl * SYNC_STRIDE, (unsigned)(G * (p.L - 1 - s)), status, dead);
+            rs_wait(cnt0 + (size_t)tl * SYNC_STRIDE, (unsigned)(G * (p.L - 1 - s)), status, dead, p.spin);
             issue_half(gt, tnext, true, 0);
         }
         STAMP(1);
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rs_bwd_kernel(LstmRB p) {
                 else if (DEEP) {
                     asm volatile("" : "+v"(pv));
                     if (has_next && !next_first && pv < (unsigned)(G * (p.L - 1 - s1)))
-                        rs_wait(cnt0 + (size_t)tl1 * SYNC_STRIDE, (unsigned)(G * (p.L - 1 - s1)), status, dead);
+                        rs_wait(cnt0 + (size_t)tl1 * SYNC_STRIDE, (unsigned)(G * (p.L - 1 - s1)), status, dead, p.spin);
                     issue_half(tile0 + tl1, dir ? t1 - 1 : t1 + 1, has_next && !next_first, 0);
                 }
                 const bf16* sb = stage + sq * LDQ + rg * 8;
@@ -935,6 +938,16 @@ static __global__ void rs_status_fold_kernel(unsigned* __restrict__ flag, unsign
     }
 }
 
+// Polls a hand-off wait makes before it gives up and raises the status words (one process-wide value for the
+// register- and LDS-stationary kernels; a poll is ~1 us).  The default (~8 s) rides out the rank skew of a data-parallel
+// job whose collectives hold CUs while they wait for a peer (first steps, graph captures); tests set a small value.
+static unsigned g_spin_limit = SPIN_LIMIT_DEFAULT;
+unsigned dtt_handoff_spin_limit_value() { return g_spin_limit; }
+extern "C" int dtt_lstm_handoff_spin_limit(unsigned polls) {
+    g_spin_limit = polls ? polls : SPIN_LIMIT_DEFAULT;
+    return 0;
+}
+
 extern "C" int dtt_lstm_rs_status_fold(unsigned* flag, int clear, void* stream) {
     hipLaunchKernelGGL(rs_status_fold_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), flag, 1u, clear);
     DTT_LAUNCH_CHECK();
@@ -971,7 +984,7 @@ extern "C" int dtt_lstm_rs_fwd(const void* xg, const void* whh, void* y, void* g
     while ((1 << hshift) < heads) ++hshift;
     DTT_CHECK((1 << hshift) == heads && heads <= 32, "dtt_lstm_rs_fwd: heads = %d is not a power of two <= 32", heads);
     DTT_CHECK((int64_t)N * L * 2 * 4 * H * 2 < (1LL << 32) - 64, "dtt_lstm_rs_fwd: xg exceeds 32-bit byte offsets");
-    LstmRF p{xg, whh, y, gates_blk, cst_blk, sync, N, L, hshift, S, NT, TMAX};
+    LstmRF p{xg, whh, y, gates_blk, cst_blk, sync, N, L, hshift, S, NT, TMAX, dtt_handoff_spin_limit_value()};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     { const int nw = dtt_lstm_rs_sync_words(N, H); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
     const dim3 grid(rs_grid(2 * S * G)), block(256);
@@ -1004,7 +1017,7 @@ extern "C" int dtt_lstm_rs_bwd(const void* dy, const void* gates_blk, const floa
     while ((1 << hshift) < heads) ++hshift;
     DTT_CHECK((1 << hshift) == heads && heads <= 32, "dtt_lstm_rs_bwd: heads = %d is not a power of two <= 32", heads);
     DTT_CHECK((int64_t)N * L * 2 * 4 * H * 2 < (1LL << 32) - 64, "dtt_lstm_rs_bwd: dG exceeds 32-bit byte offsets");
-    LstmRB p{dy, gates_blk, cst_blk, whhT, dG, dcbuf, dbias, sync, N, L, hshift, S, NT, TMAX};
+    LstmRB p{dy, gates_blk, cst_blk, whhT, dG, dcbuf, dbias, sync, N, L, hshift, S, NT, TMAX, dtt_handoff_spin_limit_value()};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     { const int nw = dtt_lstm_rs_sync_words(N, H); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
     const dim3 grid(rs_grid(2 * S * G)), block(256);

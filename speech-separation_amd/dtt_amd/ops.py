@@ -979,6 +979,14 @@ def handoff_kernels(enabled=True):
     _HANDOFF = bool(enabled)
 
 
+def handoff_spin_limit(polls=0):
+    """Polls (~1 us each) a hand-off wait makes before it gives up and raises the status words; 0 = the default of
+    2^23 (~8 s), long enough for a data-parallel job's rank skew (a collective that waits for a peer can hold CUs
+    the launch needs: first steps, graph captures on other ranks).  A time-out raises DttError at the next poll /
+    check; it never goes unreported."""
+    check(lib().dtt_lstm_handoff_spin_limit(C.c_uint(int(polls))), "dtt_lstm_handoff_spin_limit")
+
+
 # --------------------------------------------------------------------------- #
 # Hand-off health: the product reads the status words
 # --------------------------------------------------------------------------- #

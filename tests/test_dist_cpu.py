@@ -90,3 +90,23 @@ def test_bucket_reducer_matches_single_process_mean():
         y.pow(2).mean().backward()
         ref = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
         assert torch.allclose(torch.from_numpy(got[step]), ref, atol=1e-6), step
+
+
+def test_local_grads_keeps_the_reducer_surface():
+    """LocalGrads (the reducer stand-in when ShardedClipAdamW exchanges the gradients) must offer what the training
+    loop, bench.py and GraphedTrainStep call on a GradBucketReducer, and leave local gradients alone."""
+    from dtt_amd.dist import GradBucketReducer, LocalGrads
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    m[0].bias.requires_grad = False
+    lg = LocalGrads(m)
+    for name in ("zero_grad", "finish", "reduce_grads", "pause_hooks", "abort_step", "capturable_collectives"):
+        assert callable(getattr(lg, name)) and callable(getattr(GradBucketReducer, name)), name
+    assert lg.world == 1 and lg.capturable_collectives() is False and len(lg.params) == 3
+    m(torch.randn(5, 4)).sum().backward()
+    g = [p.grad.clone() for p in lg.params]
+    lg.finish()
+    assert all(torch.equal(a, p.grad) for a, p in zip(g, lg.params))
+    lg.zero_grad()
+    assert all(p.grad is None for p in lg.params)
+    lg.reduce_grads(lg.params, g)
+    assert all(p.grad is a for a, p in zip(g, lg.params))

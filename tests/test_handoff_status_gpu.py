@@ -14,6 +14,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _short_waits():
+    """The product's default wait (~8 s, sized for rank skew) would make every starved launch of this file take that
+    long: 2^17 polls (~0.1 s) here."""
+    from dtt_amd import ops
+    ops.handoff_spin_limit(1 << 17)
+    yield
+    ops.handoff_spin_limit(0)
+
+
 def _idp(heads=2, Cc=512):
     from dtt_amd.model import IDPModule
     m = IDPModule(heads, Cc).to(DEV)

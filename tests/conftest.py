@@ -56,9 +56,12 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(autouse=True)
 def _pack_plan_off():
-    """dtt_amd.GraphedTrainStep switches the process-wide pack plan (ops._PackPlan) on: never into the next test."""
+    """dtt_amd.GraphedTrainStep and bench.build_workload switch the process-wide pack plan (ops._PackPlan) on, tests
+    switch the side streams: never into the next test."""
     yield
     mod = sys.modules.get("dtt_amd.ops")
     if mod is not None:
         mod.weight_plan(False)
         mod.handoff_kernels(True)
+        mod.wgrad_lane(os.environ.get("DTT_WGRAD_LANE", "1") == "1")
+        mod.video_lane(os.environ.get("DTT_VIDEO_LANE", "1") == "1")

@@ -90,20 +90,20 @@ class DttGemm(C.Structure):
 
 def gemm_raw(**kw):
     """Launch dtt_gemm from keyword fields (tensors for A/B/C/bias/R)."""
-    g = DttGemm()
     keep = []
     for k in ("A", "B", "C", "bias", "R"):
-        t = kw.pop(k, None)
+        t = kw.get(k)
         if t is not None:
             if not t.is_cuda:
                 raise DttError("dtt_amd ops need CUDA(HIP) tensors; there is no CPU path")
             keep.append(t)
-            setattr(g, k, t.data_ptr())
+            kw[k] = t.data_ptr()
+        elif k in kw:
+            del kw[k]
     kw.setdefault("batch", 1)
     kw.setdefault("splitk", 1)
     kw.setdefault("alpha", 1.0)
-    for k, v in kw.items():
-        setattr(g, k, v)
+    g = DttGemm(**kw)                  # fields set by ctypes' initialiser, not by ~25 Python-level setattr calls
     if g.atomic and g.splitk > 1:
         # split-K partial tiles through a scratch buffer instead of fp32 atomics where the kernel can use one
         need = lib().dtt_gemm_ws_bytes(C.byref(g))

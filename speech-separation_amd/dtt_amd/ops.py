@@ -62,7 +62,7 @@ def reset_zero_arena():
 # --------------------------------------------------------------------------- #
 class _Lane:
     def __init__(self):
-        self.stream, self.pending, self.keep, self.cb = None, False, [], False
+        self.stream, self.pending, self.keep, self.cb, self.fork = None, False, [], False, None
 
 
 _LANES = {}
@@ -93,7 +93,14 @@ class _lane:
         ln = _LANES.setdefault(_dev_index(self.dev), _Lane())
         if ln.stream is None:
             ln.stream = torch.cuda.Stream(self.dev)
-        ln.stream.wait_stream(torch.cuda.current_stream(self.dev))
+            ln.fork = torch.cuda.Event()
+        # fork: one event, re-recorded per fork (a wait binds to the record that precedes it); wait_stream() would build
+        # an Event object and resolve the current stream in Python each time: 50 us x 135 forks per step
+        if torch.cuda.current_device() == ln.stream.device_index:
+            ln.fork.record()
+            ln.stream.wait_event(ln.fork)
+        else:
+            ln.stream.wait_stream(torch.cuda.current_stream(self.dev))
         ln.keep.extend(self.keep)
         ln.pending = True
         if not ln.cb:

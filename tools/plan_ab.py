@@ -1,5 +1,6 @@
+"""Same-box A/B of the weight pack plan on the eagerly issued step: PLAN=0|1 python tools/plan_ab.py [workload]"""
 import argparse, os, sys, time, torch
-ROOT="/root/repo"
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+"/speech-separation_amd")
 import bench
 from dtt_amd import ops

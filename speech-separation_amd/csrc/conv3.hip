@@ -8,6 +8,7 @@
 //   conv3x3_wgrad_kernel (bf16): dw[co][tap][ci] += sum_px dy[px][co] * x[px+tap][ci]
 //       pixels are the MFMA K dimension; operands are read from the natural
 //       [pixel][channel] LDS image with the transposing ds_read_b64_tr_b16.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/dtt_hip.h"
 
@@ -51,7 +52,8 @@ template <typename T, int TN, bool RES>
 __device__ __forceinline__ void conv3_epilogue(const Conv3P& p, f32x16_t (&acc)[2][TN], float* stage, const float (&bsv)[TN],
                                                int b, int tf, int tt, int co0, RunStat* run = nullptr) {
     constexpr int BN = 32 * TN, SW = BN + 4, E = Vec16<T>::N, CPP = BN / E, NIT = CPP;   // 64 px * CPP chunks / 64 lanes
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    // (wave: the wave's 4-row slab of the tile; kernels with eight waves give waves 4-7 the next 32 output channels)
+    const int tid = threadIdx.x, wave = (tid >> 6) & 3, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int f0 = tf * TH, t0 = tt * TW;
     T* y = reinterpret_cast<T*>(p.y) + (int64_t)b * p.F * p.T * p.Co;
     const T* res = RES ? reinterpret_cast<const T*>(p.res) + (int64_t)b * p.F * p.T * p.Co : nullptr;
@@ -327,41 +329,196 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(Conv3P p, int tiles
     flush();
 }
 
+// Ci = Co = 64, bf16 (the second U-Net level: 257 x 63 planes).  conv3x3_s1_kernel spends its time at B = 16 on the
+// per-chunk chain load -> LDS -> barrier -> MFMA of workgroups that live for one tile (~12 us per round of resident
+// workgroups against 1.9 us of MFMA, DESIGN finding 35).  Here, as in the 32-channel kernel, ONE persistent workgroup
+// per CU walks its tiles: eight waves = 4 row slabs x 2 halves of the output channels; all 9 x 64 x 64 weights stay in
+// LDS for the whole launch (83 KB; as register fragments they would be 144 registers per wave: spills at two waves
+// per SIMD); the whole 64-channel patch of a tile is one LDS image (no channel chunks, no barrier inside a tile); the
+// next tile's patch travels through registers while the current one is in the MFMAs.  The fp32 staging slabs of the
+// epilogue (74 KB) overlay the patch (51 KB): weights + max(patch, slabs) = 157 KB of the CU's 160.
+// Per tile: MFMAs(i) | barrier | epilogue(i) | barrier | patch(i+1) registers -> LDS, prefetch(i+2) issued | barrier.
+constexpr int C64_LDC = 72, C64_NPC = PH * PW * 8, C64_NIT = (C64_NPC + 511) / 512, C64_SW = 36;
+constexpr int C64_ROWP = PatchPitch<bf16, C64_LDC>::ROWP;
+constexpr size_t C64_WBYTES = (size_t)9 * 64 * C64_LDC * sizeof(bf16);
+constexpr size_t C64_PBYTES = (size_t)PH * C64_ROWP * sizeof(bf16), C64_SBYTES = (size_t)8 * 64 * C64_SW * sizeof(float);
+constexpr size_t C64_SMEM = C64_WBYTES + (C64_PBYTES > C64_SBYTES ? C64_PBYTES : C64_SBYTES);
+// The MFMA phase of a tile as 36 (tap, k-step) items of two MFMAs, with the three fragment reads of item i + 2 issued
+// ahead of the MFMAs of item i.  In asm, with counted waits: left to the compiler every ds_read sinks to its MFMA behind
+// s_waitcnt lgkmcnt(0..1) (also from source-level double buffering with scheduling barriers), and the phase takes 3.5 us
+// per tile instead of the 1.9 us of its MFMAs.
+typedef __attribute__((address_space(3))) void* c64_lptr_t;
+struct C64Frag { s16x8_t b, a0, a1; };
+constexpr int C64_WREG = 2;            // k-steps (of 4) whose weight fragments a wave keeps in registers: 18 x 4 registers
+template <int IT> constexpr int c64_nreads() { return (IT & 3) < C64_WREG ? 2 : 3; }
+template <int IT>
+__device__ __forceinline__ void c64_read(C64Frag& f, unsigned wb0, unsigned wb1, unsigned a0, unsigned a1) {
+    constexpr int tap = IT >> 2, s = IT & 3, kh = tap / 3, kw = tap % 3;
+    constexpr int ob = ((tap % 5) * 64 * C64_LDC + s * 16) * 2;          // taps 5-8 from a second base: 16-bit offsets
+    constexpr int oa = (kh * C64_ROWP + kw * C64_LDC + s * 16) * 2;
+    if constexpr (s < C64_WREG)
+        asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
+                     : "=&v"(f.a0), "=&v"(f.a1) : "v"(a0), "v"(a1), "n"(oa));
+    else
+        asm volatile("ds_read_b128 %0, %3 offset:%6\n\tds_read_b128 %1, %4 offset:%7\n\tds_read_b128 %2, %5 offset:%7"
+                     : "=&v"(f.b), "=&v"(f.a0), "=&v"(f.a1)
+                     : "v"(tap < 5 ? wb0 : wb1), "v"(a0), "v"(a1), "n"(ob), "n"(oa));
+}
+template <int N>
+__device__ __forceinline__ void c64_fence(C64Frag& f) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f.b), "+v"(f.a0), "+v"(f.a1) : "n"(N));
+}
+template <int IT>
+__device__ __forceinline__ void c64_items(C64Frag (&f)[3], const s16x8_t (&wreg)[9][C64_WREG], unsigned wb0, unsigned wb1,
+                                          unsigned a0, unsigned a1, f32x16_t& acc0, f32x16_t& acc1) {
+    if constexpr (IT + 2 < 36) c64_read<IT + 2>(f[(IT + 2) % 3], wb0, wb1, a0, a1);
+    // reads still in flight behind item IT's: those of items IT + 1 and IT + 2
+    c64_fence<(IT + 1 < 36 ? c64_nreads<IT + 1>() : 0) + (IT + 2 < 36 ? c64_nreads<IT + 2>() : 0)>(f[IT % 3]);
+    if constexpr ((IT & 3) < C64_WREG) {
+        MM<bf16>::mma(f[IT % 3].a0, wreg[IT >> 2][IT & 3], acc0);
+        MM<bf16>::mma(f[IT % 3].a1, wreg[IT >> 2][IT & 3], acc1);
+    } else {
+        MM<bf16>::mma(f[IT % 3].a0, f[IT % 3].b, acc0);
+        MM<bf16>::mma(f[IT % 3].a1, f[IT % 3].b, acc1);
+    }
+    if constexpr (IT + 1 < 36) c64_items<IT + 1>(f, wreg, wb0, wb1, a0, a1, acc0, acc1);
+}
+
+template <bool RES>
+__global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(Conv3P p, int tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem64[];
+    bf16* wl = reinterpret_cast<bf16*>(smem64);                           // [9][64 co][72]
+    bf16* patch = reinterpret_cast<bf16*>(smem64 + C64_WBYTES);           // [PH][ROWP]
+    float* stage_all = reinterpret_cast<float*>(smem64 + C64_WBYTES);     // overlays the patch between two barriers
+    const int tid = threadIdx.x, wave = tid >> 6, wm = wave & 3, wn = wave >> 2, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const bf16* wp = reinterpret_cast<const bf16*>(p.wp);                 // [Co][9][Ci]
+
+    const int per_b = p.tiles_f * p.tiles_t, total = p.B * per_b;
+    const int tile0 = blockIdx.x * tiles_per_wg, tile1 = min(total, tile0 + tiles_per_wg);
+    if (tile0 >= tile1) return;
+    Vec16<bf16> pre[C64_NIT];
+    auto prefetch = [&](int tile) {
+        const int b = tile / per_b, rr = tile - b * per_b, tf = rr / p.tiles_t, tt = rr - tf * p.tiles_t;
+        const bf16* x = reinterpret_cast<const bf16*>(p.x) + (int64_t)b * p.F * p.T * 64;
+#pragma unroll
+        for (int it = 0; it < C64_NIT; ++it) {
+            const int idx = tid + it * 512, pp = idx >> 3, ch = idx & 7;
+            const int pf = pp / PW, pt = pp - pf * PW;
+            const int f = tf * TH - 1 + pf, t = tt * TW - 1 + pt;
+            pre[it] = ld16_pred<bf16>(x + ((int64_t)f * p.T + t) * 64 + ch * 8, x,
+                                      idx < C64_NPC && f >= 0 && f < p.F && t >= 0 && t < p.T);
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int it = 0; it < C64_NIT; ++it) {
+            const int idx = tid + it * 512;
+            if (idx < C64_NPC) { const int pix = idx >> 3; st16<bf16>(patch + (pix / PW) * C64_ROWP + (pix % PW) * C64_LDC + (idx & 7) * 8, pre[it]); }
+        }
+    };
+    prefetch(tile0);
+    // weights: 9 * 64 rows of 64 channels = 4608 16-byte pieces, [co][tap][ci] in memory -> [tap][co][72] in LDS
+    {   // (all nine loads of a thread in flight before the first store: as a rolled load -> store loop this prologue
+        // was nine serial round trips to L2, a third of the launch at B = 16)
+        Vec16<bf16> wv[9];
+#pragma unroll
+        for (int it = 0; it < 9; ++it) wv[it] = ld16<bf16>(wp + (int64_t)(tid + it * 512) * 8);
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {
+            const int idx = tid + it * 512, row = idx >> 3, ch = idx & 7, co = row / 9, tap = row - co * 9;
+            st16<bf16>(wl + (tap * 64 + co) * C64_LDC + ch * 8, wv[it]);
+        }
+    }
+    float bsv[1];
+    conv3_bias<1>(p, wn * 32, bsv);
+    RunStat run{0.f, 0.f, 0.f, 0.f, false};
+    int run_b = -1;
+    const int nslot = (per_b + tiles_per_wg - 1) / tiles_per_wg + 1;
+    auto flush = [&]() {
+        if (!run.open || !p.partial) return;
+        const float a1 = run.s1 + __shfl_xor(run.s1, 32, 64), a2 = run.s2 + __shfl_xor(run.s2, 32, 64);
+        if (lh == 0) {
+            const float dm = run.n > 0.f ? a1 / run.n : 0.f;
+            const int slot = blockIdx.x - (run_b * per_b) / tiles_per_wg;
+            float* d = p.partial + ((((int64_t)run_b * nslot + slot) * 4 + wm) * 64 + wn * 32 + lr) * 3;
+            d[0] = run.piv + dm; d[1] = fmaxf(a2 - a1 * dm, 0.f); d[2] = run.n;
+        }
+        run.open = false;
+    };
+    park();
+    __syncthreads();
+    if (tile0 + 1 < tile1) prefetch(tile0 + 1);
+    s16x8_t wreg[9][C64_WREG];                              // the weight fragments of the first k-steps stay in registers:
+#pragma unroll                                              // the MFMA phase is bound by LDS bandwidth (3 reads per 2 MFMAs)
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int s = 0; s < C64_WREG; ++s) wreg[tap][s] = MM<bf16>::ldfrag(wl + (tap * 64 + wn * 32 + lr) * C64_LDC + s * 16 + lh * 8);
+    // LDS byte addresses of the lane's fragment pieces: weights (two bases, see c64_read), patch rows of its two halves
+    const unsigned wb0 = (unsigned)(uintptr_t)(c64_lptr_t)wl + ((wn * 32 + lr) * C64_LDC + lh * 8) * 2;
+    const unsigned wb1 = wb0 + 5 * 64 * C64_LDC * 2;
+    const unsigned pb = (unsigned)(uintptr_t)(c64_lptr_t)patch + ((lr & 15) * C64_LDC + lh * 8) * 2;
+    const unsigned ab0 = pb + (wm * 4 + (lr >> 4)) * C64_ROWP * 2, ab1 = ab0 + 2 * C64_ROWP * 2;
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int b = tile / per_b, rr = tile - b * per_b, tf = rr / p.tiles_t, tt = rr - tf * p.tiles_t;
+        if (b != run_b) { flush(); run_b = b; }
+        f32x16_t acc[2][1];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][0][r] = 0.f;
+        C64Frag fr[3];
+        asm volatile("" ::: "memory");                      // (the asm reads below are LDS accesses the compiler cannot see)
+        c64_read<0>(fr[0], wb0, wb1, ab0, ab1);
+        c64_read<1>(fr[1], wb0, wb1, ab0, ab1);
+        c64_items<0>(fr, wreg, wb0, wb1, ab0, ab1, acc[0][0], acc[1][0]);
+        asm volatile("" ::: "memory");
+        __syncthreads();                                    // every wave is done reading patch(i): the slabs may overlay it
+        conv3_epilogue<bf16, 1, RES>(p, acc, stage_all + wave * 64 * C64_SW, bsv, b, tf, tt, wn * 32, p.partial ? &run : nullptr);
+        __syncthreads();                                    // every wave is done with its slab
+        if (tile + 1 < tile1) park();
+        if (tile + 2 < tile1) prefetch(tile + 2);
+        __syncthreads();                                    // patch(i+1) is visible
+    }
+    flush();
+}
+
 // stats[b][c] = {mean, rstd} from the per-(workgroup, wave) partials of conv3x3_c32_kernel: a few dozen
 // {mean, M2, n} triples per channel, merged in two plain passes by one thread per channel.
 __global__ __launch_bounds__(1024) void conv_c32_stats_finalize(const float* __restrict__ partial, float* __restrict__ stats,
-                                                                int per_b, int tiles_per_wg, int total, float ntot, float eps) {
+                                                                int per_b, int tiles_per_wg, int total, float ntot, float eps,
+                                                                int C) {
     __shared__ float sh[32][33];
     __shared__ float gmean[32];
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5, b = blockIdx.x;
+    // C channels (32: conv3x3_c32_kernel, 64: conv3x3_c64_kernel), 32 per workgroup (blockIdx.y)
+    const int cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, g = threadIdx.x >> 5, b = blockIdx.x;
     const int nslot = (per_b + tiles_per_wg - 1) / tiles_per_wg + 1;
     const int wg0 = (b * per_b) / tiles_per_wg, wg1 = min(((b + 1) * per_b - 1) / tiles_per_wg, (total - 1) / tiles_per_wg);
     const int nitem = (wg1 - wg0 + 1) * 4;                 // (slot, wave) pairs, contiguous in the buffer
-    const float* base = partial + (int64_t)b * nslot * 4 * 32 * 3 + c * 3;
+    const float* base = partial + (int64_t)b * nslot * 4 * C * 3 + c * 3;
     float acc = 0.f;
-    for (int i = g; i < nitem; i += 32) { const float* d = base + i * 32 * 3; acc += d[2] * d[0]; }
-    sh[g][c] = acc;
+    for (int i = g; i < nitem; i += 32) { const float* d = base + (int64_t)i * C * 3; acc += d[2] * d[0]; }
+    sh[g][cl] = acc;
     __syncthreads();
     if (g == 0) {
         float t = 0.f;
-        for (int q = 0; q < 32; ++q) t += sh[q][c];
-        gmean[c] = t / ntot;
+        for (int q = 0; q < 32; ++q) t += sh[q][cl];
+        gmean[cl] = t / ntot;
     }
     __syncthreads();
-    const float mean = gmean[c];
+    const float mean = gmean[cl];
     acc = 0.f;
     for (int i = g; i < nitem; i += 32) {
-        const float* d = base + i * 32 * 3;
+        const float* d = base + (int64_t)i * C * 3;
         const float dd = d[0] - mean;
         acc += d[2] > 0.f ? d[1] + d[2] * dd * dd : 0.f;
     }
-    sh[g][c] = acc;
+    sh[g][cl] = acc;
     __syncthreads();
     if (g == 0) {
         float t = 0.f;
-        for (int q = 0; q < 32; ++q) t += sh[q][c];
-        stats[((int64_t)b * 32 + c) * 2] = mean;
-        stats[((int64_t)b * 32 + c) * 2 + 1] = rsqrtf(t / ntot + eps);
+        for (int q = 0; q < 32; ++q) t += sh[q][cl];
+        stats[((int64_t)b * C + c) * 2] = mean;
+        stats[((int64_t)b * C + c) * 2 + 1] = rsqrtf(t / ntot + eps);
     }
 }
 
@@ -684,7 +841,27 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
         else hipLaunchKernelGGL(conv3x3_c32_kernel<false>, dim3((total + tpw - 1) / tpw), dim3(256), 0, ST, p, tpw);
         if (partial && stats)
             hipLaunchKernelGGL(conv_c32_stats_finalize, dim3(B), dim3(1024), 0, ST, partial, stats, p.tiles_f * p.tiles_t,
-                               tpw, total, (float)F * (float)T, eps);
+                               tpw, total, (float)F * (float)T, eps, 32);
+        DTT_LAUNCH_CHECK();
+        return 0;
+    }
+    static const bool c64_on = [] { const char* e = getenv("DTT_CONV_C64"); return !(e && e[0] == '0'); }();
+    if (dtype == 1 && Ci == 64 && Co == 64 && c64_on) {
+        const int total = B * p.tiles_f * p.tiles_t;
+        const int tpw = max(1, (total + 255) / 256);         // one persistent workgroup per CU
+        auto kr = conv3x3_c64_kernel<true>;
+        auto kn = conv3x3_c64_kernel<false>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM);
+            hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM);
+            attr_set = true;
+        }
+        if (res) hipLaunchKernelGGL(kr, dim3((total + tpw - 1) / tpw), dim3(512), C64_SMEM, ST, p, tpw);
+        else hipLaunchKernelGGL(kn, dim3((total + tpw - 1) / tpw), dim3(512), C64_SMEM, ST, p, tpw);
+        if (partial && stats)
+            hipLaunchKernelGGL(conv_c32_stats_finalize, dim3(B, 2), dim3(1024), 0, ST, partial, stats, p.tiles_f * p.tiles_t,
+                               tpw, total, (float)F * (float)T, eps, 64);
         DTT_LAUNCH_CHECK();
         return 0;
     }

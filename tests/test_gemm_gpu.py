@@ -233,6 +233,30 @@ def test_gemm_row_shift(dt):
         assert rel_err(c, ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("Cc", [32, 64])
+def test_conv3x3_persistent_kernels_walk_tiles_across_batch_items(Cc):
+    """conv3x3_c32_kernel / conv3x3_c64_kernel (block_tfc_tdf.py:12-17 at the two upper U-Net levels): one workgroup
+    per CU walks several tiles, and with 81 tiles per item and 2 per workgroup a walk straddles two batch items -- the
+    running InstanceNorm sums must be flushed per item.  Output, residual form and statistics against fp64."""
+    from dtt_amd import ops
+    g = torch.Generator().manual_seed(700 + Cc)
+    dev, dt = "cuda", torch.bfloat16
+    Bn, Fq, T = 5, 130, 131
+    x = _mk((Bn, Cc, Fq, T), dt, g)
+    w = (_mk((Cc, Cc, 3, 3), dt, g).float() / (3 * Cc ** 0.5)).to(dt)
+    bias = torch.randn(Cc, generator=g)
+    res = _mk((Bn, Cc, Fq, T), dt, g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    wp = w.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc).contiguous().to(dev)
+    xd = _nhwc(x).to(dev)
+    y, stats = ops.conv3x3_s1(xd, wp, bias.to(dev), want_stats=True)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL[dt]
+    assert rel_err(stats[..., 0], ref.mean(dim=(2, 3))) < 2e-3
+    assert rel_err(stats[..., 1], 1.0 / torch.sqrt(ref.var(dim=(2, 3), unbiased=False) + 1e-5)) < 2e-3
+    y2, _ = ops.conv3x3_s1(xd, wp, bias.to(dev), res=_nhwc(res).to(dev))
+    assert rel_err(y2.permute(0, 3, 1, 2), ref + res.double()) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Ci,Co,Fq,T", [(32, 32, 33, 20), (64, 64, 17, 13), (32, 96, 16, 16), (128, 64, 9, 35),
                                           (64, 64, 22, 22), (64, 128, 38, 17), (128, 128, 65, 16)])

@@ -26,6 +26,7 @@ def _pit_l1(sources, preds, batch, fixed):
         raise DttError("dtt_amd losses run on an MI355X only (no CPU path)")
     src = ([s["spectrogram"] for s in sources] + [s["phase"] for s in sources] + [s["audio"] for s in sources])
     ops.handoff_poll(pspec.device)          # hand-off LSTM kernels of this forward / the previous step: non-blocking
+    ops.join_video_lane()                   # targets a caller produced on the side stream (video_stream.defer)
     item, permuts = ops.PitL1Loss.apply(pspec, pphase, paudio, fixed, *src)
     return item, permuts
 
@@ -34,6 +35,7 @@ class DTTNetLoss(nn.Module):
     """Per-item L1 loss of one (prediction, target) pair -> [B]  (dttnet_loss.py:13-34)."""
 
     def forward(self, audio_true, spectrogram_true, phase_true, audio_pred, spectrogram_pred, phase_pred):
+        ops.join_video_lane()
         item, _ = ops.PitL1Loss.apply(spectrogram_pred.unsqueeze(0), phase_pred.unsqueeze(0),
                                       audio_pred.unsqueeze(0), True, spectrogram_true, phase_true, audio_true)
         return item

@@ -170,6 +170,26 @@ class video_stream:
                 t.record_stream(cur)                   # allocated on the side stream's pool, consumed on this one
         return tensors[0] if len(tensors) == 1 else tensors
 
+    def defer(self, *tensors):
+        """Join later: the loss wrappers call join_video_lane() before they read their inputs (tensors produced on the
+        side stream that only the loss consumes, e.g. the sources' spectrograms)."""
+        if self.st is not None:
+            _VIDEO_DEFER.setdefault(_dev_index(self.dev), []).extend(tensors)
+
+
+_VIDEO_DEFER = {}
+
+
+def join_video_lane():
+    """The launch stream waits for work deferred on the side stream (video_stream.defer); a no-op otherwise."""
+    for idx, ts in _VIDEO_DEFER.items():
+        if ts:
+            cur = torch.cuda.current_stream(torch.device("cuda", idx))
+            cur.wait_stream(_VIDEO_STREAMS[idx])
+            for t in ts:
+                t.record_stream(cur)
+            ts.clear()
+
 
 # --------------------------------------------------------------------------- #
 # thin wrappers over the C entry points

@@ -130,14 +130,17 @@ def join_wgrad_lane():
 
 
 _VIDEO_LANE = [os.environ.get("DTT_VIDEO_LANE", "1") == "1"]
+# the fork is recorded into HIP graphs too: a replay overlaps branches that fork at the graph's root (the lip encoder's
+# forward: cfg4 replay 39.10 -> 38.32 ms), not those that fork mid-chain (DESIGN finding 43)
+_VIDEO_IN_GRAPH = os.environ.get("DTT_VIDEO_LANE_GRAPH", "1") == "1"
 _VIDEO_STREAMS = {}
 
 
 def video_lane(enabled=True):
     """The lip encoder's forward depends on nothing but the clip, and its backward on nothing but the fusion's gradient:
     with the lane enabled the models run it on a stream of its own beside the audio encoder (autograd runs a node's
-    backward on the stream of its forward and orders the streams where gradients cross).  Not used while a HIP graph
-    is being captured (the graphed step keeps one branch)."""
+    backward on the stream of its forward and orders the streams where gradients cross).  Recorded into HIP graphs as
+    well (DTT_VIDEO_LANE_GRAPH=0: one branch)."""
     _VIDEO_LANE[0] = bool(enabled)
 
 
@@ -148,7 +151,7 @@ class video_stream:
         self.dev, self.st, self.ctx = dev, None, None
 
     def __enter__(self):
-        if _VIDEO_LANE[0] and self.dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+        if _VIDEO_LANE[0] and self.dev.type == "cuda" and (_VIDEO_IN_GRAPH or not torch.cuda.is_current_stream_capturing()):
             self.st = _VIDEO_STREAMS.get(_dev_index(self.dev))
             if self.st is None:
                 self.st = _VIDEO_STREAMS[_dev_index(self.dev)] = torch.cuda.Stream(self.dev)

@@ -240,7 +240,9 @@ void dtt_lstm_cluster_diag_drop_workgroups(int n);
  * parameters that the reference's modules get from autocast and from PyTorch's own weight layouts
  * (block_tfc_tdf.py:12-32 conv weights, latent.py:87-96 LSTM / Linear weights, ...) are strided copies with an
  * optional fp32 -> bf16 cast.  descs: device table; chunks: device table of int32 pairs (descriptor index, chunk
- * index), one workgroup each, dtt_multi_pack_chunk() elements per chunk, row-major over `shape`. */
+ * index), one workgroup each, chunk indices 0 .. dtt_multi_pack_nchunks(desc) - 1 per descriptor (contiguous casts
+ * go by vectors, transposing copies by tiles through LDS, the rest dtt_multi_pack_chunk() elements at a time,
+ * row-major over `shape`: dims ordered by destination stride, numel < 2^31). */
 typedef struct DttPackDesc {
     const void* src; void* dst;
     int64_t sstride[4], dstride[4];   /* element strides */
@@ -249,6 +251,7 @@ typedef struct DttPackDesc {
     int32_t src_dtype, dst_dtype;     /* 0 = float32, 1 = bfloat16 */
 } DttPackDesc;
 int dtt_multi_pack_chunk(void);
+int64_t dtt_multi_pack_nchunks(const DttPackDesc* desc);
 int dtt_multi_pack(const DttPackDesc* descs, const int32_t* chunks, int nchunks, void* stream);
 
 /* ---------------------------------------------------------------------------

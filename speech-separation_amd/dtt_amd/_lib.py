@@ -31,6 +31,7 @@ def lib():
         _lib.dtt_version.restype = C.c_int
         _lib.dtt_gemm_ws_bytes.restype = C.c_int64
         _lib.dtt_conv3x3_wgrad_ws_bytes.restype = C.c_int64
+        _lib.dtt_multi_pack_nchunks.restype = C.c_int64
     return _lib
 
 

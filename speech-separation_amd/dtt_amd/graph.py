@@ -84,11 +84,12 @@ class GraphedTrainStep:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.graph = torch.cuda.CUDAGraph()
         self._replays = 0
-        # derived weight tensors from one launch per step (ops._PackPlan), recorded by the first warm-up step.  Opt-in
-        # (pack_plan=True or DTT_PACK_PLAN=1): measured on cfg4 the graph replay does not get faster (47.3 ms with the
-        # plan, 46.5 without: ~400 tiny launches cost ~2 us each inside a graph, the table-driven kernel 0.5 ms)
+        # derived weight tensors from one launch per step (ops._PackPlan), recorded by the first warm-up step.  On by
+        # default since the table-driven kernel copies by vectors and tiles (0.26 ms instead of 0.6: cfg4 replay 39.55
+        # -> 39.0 ms, same box, twice); pack_plan=False or DTT_PACK_PLAN=0 keeps the ~400 tiny launches (~2 us each
+        # inside a graph)
         if pack_plan is None:
-            pack_plan = os.environ.get("DTT_PACK_PLAN", "0") == "1"
+            pack_plan = os.environ.get("DTT_PACK_PLAN", "1") != "0"
         prev_plan = ops._PLAN.enabled
         ops.weight_plan(pack_plan)
         # handoff_kernels=False (or DTT_GRAPH_HANDOFF=0) keeps the cross-CU hand-off LSTM kernels (H >= 512) out of

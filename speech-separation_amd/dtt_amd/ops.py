@@ -456,6 +456,28 @@ def _merge_dims(shape, ss, ds):
     return out or [(1, 1, 1)]
 
 
+class _StridedSource:
+    """A source view torch cannot express (negative strides: the data-gradient conv packs walk the 3 x 3 taps
+    backwards), for a pack-plan pair: element strides and offset relative to `base`, and `now()` = the same values as
+    a real tensor (the recording step's copy)."""
+
+    def __init__(self, base, shape, strides, offset, now):
+        self.base, self.shape, self._strides, self.offset, self.now = base, tuple(shape), tuple(strides), offset, now
+        self.dtype = base.dtype
+
+    def stride(self):
+        return self._strides
+
+    def numel(self):
+        n = 1
+        for k in self.shape:
+            n *= k
+        return n
+
+    def data_ptr(self):
+        return self.base.data_ptr() + self.offset * self.base.element_size()
+
+
 class _PackPlan:
     """A training step derives ~400 small tensors from its parameters (bf16 casts, conv weights in tap-major
     order, stacked / transposed LSTM weights, padded TDF weights, ...): one 5 us launch each, strung between
@@ -465,10 +487,11 @@ class _PackPlan:
     buffers with one dtt_multi_pack launch (pack.hip); the few recipes that are not plain copies (bias sums)
     run as recorded closures right behind it.  Recipes read the parameters as they are when `prepare` runs:
     parameters must not change between the start of forward and the end of backward, nor move in memory while
-    the plan is enabled (training loops satisfy this; weight_plan() forgets the plan).  Off by default, and
-    measured NOT to pay under graph replay yet: inside a HIP graph a tiny launch costs ~2 us, not the 5-7 us the
-    eager trace shows, and the table-driven kernel takes 0.5 ms (strided 4-byte reads of the transposed /
-    tap-major copies): cfg4 47.3 ms/step with the plan, 46.5 without.
+    the plan is enabled (training loops satisfy this; weight_plan() forgets the plan).  Off by default for plain eager
+    use; GraphedTrainStep and bench.py's eager mode switch it on.  The table-driven kernel first walked every copy
+    element by element (0.58 ms per cfg4 step: 4-byte reads at a stride for the transposed and tap-major copies, and
+    no gain under graph replay: 47.3 ms with the plan, 46.5 without); by vectors and LDS tiles it takes 0.26 ms (cfg4
+    replay 39.55 -> 39.0 ms, eager issue 36.3 -> 35.5).
     (A first form ran the recipes on a side stream joined in stages: as a branch of the step's HIP graph it
     made the replay 0.9 ms SLOWER than the chain of tiny launches it removed.)"""
 
@@ -486,7 +509,6 @@ class _PackPlan:
         self.enabled = enabled
 
     def build(self):
-        chunk = lib().dtt_multi_pack_chunk()
         descs, chunks = [], []
         for d, v in self.pairs:
             dims = _merge_dims(v.shape, v.stride(), d.stride())
@@ -497,7 +519,7 @@ class _PackPlan:
                 e.shape[i], e.sstride[i], e.dstride[i] = n, a, b
             e.numel = v.numel()
             e.src_dtype, e.dst_dtype = dtype_code(v.dtype), dtype_code(d.dtype)
-            for c in range(-(-v.numel() // chunk)):
+            for c in range(lib().dtt_multi_pack_nchunks(C.byref(e))):
                 chunks += [len(descs), c]
             descs.append(e)
         arr = (DttPackDesc * len(descs))(*descs)
@@ -566,7 +588,7 @@ def packed(key, recipe, spec=None):
             pr = pairs(out)
             if all(d.shape == v.shape and len(_merge_dims(v.shape, v.stride(), d.stride())) <= 4 for d, v in pr):
                 for d, v in pr:
-                    d.copy_(v)
+                    d.copy_(v.now() if isinstance(v, _StridedSource) else v)
                 pl.pairs += pr
                 pl.outs[key] = out
                 return out
@@ -607,6 +629,10 @@ def _pack_dgrad(w, kind, dt):
 
         def pairs(out):
             o4 = out.view(Ci, 3, 3, Co)
+            if w.is_contiguous():          # one descriptor: the taps as a dim of stride -1 from the last tap
+                src = _StridedSource(w, (Ci, 3, 3, Co), (9, -3, -1, 9 * Ci), 8,
+                                     lambda: w.flip(2, 3).permute(1, 2, 3, 0))
+                return [(o4, src)]
             return [(o4[:, kh, kw, :], w[:, :, 2 - kh, 2 - kw].t()) for kh in range(3) for kw in range(3)]
         return packed(_wkey("pds1", dt, w), lambda: _pack_dgrad_s1_now(w, dt), ((Ci, 9 * Co), dt, pairs))
     if kind == "down":

@@ -77,11 +77,15 @@ def _lstm(i0, fused=False):
             Cp = _v(args[i0 + 4])
             flops += 2.0 * N * L * 2 * Cp * 4 * H
             d["Cp"] = Cp
-        # (bytes 0: priced against the MFMA peak like the contraction it replaces -- SURVEY 8(d) "LSTM input +
-        # recurrent GEMMs" -- although its saved activations, 8H + 8H + 2H bf16 and 2H fp32 per row, put its
-        # intensity just below the ridge)
-        return d, flops, 0.0
+        # Priced against the MFMA peak like the contraction it replaces (SURVEY 8(d) "LSTM input + recurrent GEMMs";
+        # MFMA_PRICED below), although the saved activations of the stationary kernels -- per row and direction xg /
+        # dG 4H, gates 4H, y / dy H bf16 and c H fp32: 44 H bytes per row -- put the intensity (186 flop / byte at
+        # H = 512) below the ridge: the row carries that fraction too (`hbm_frac`).
+        return d, flops, (0.0 if fused else float(N) * L * 44 * H)
     return f
+
+
+MFMA_PRICED = ("dtt_lstm_rs_fwd", "dtt_lstm_rs_bwd", "dtt_lstm_cluster_fwd", "dtt_lstm_cluster_bwd")
 
 
 def _ew(idx, ntensors, dt_idx):
@@ -202,13 +206,15 @@ class CallTimer:
             row = dict(entry=r["entry"], shape=r["shape"], launches_per_step=round(n / nsteps, 2),
                        ms_per_step=round(tot / nsteps, 4), avg_us=round(avg_s * 1e6, 1))
             if r["flops"] > 0 or r["bytes"] > 0:
-                mfma = r["bytes"] <= 0 or r["flops"] / max(r["bytes"], 1.0) >= RIDGE
+                mfma = r["entry"] in MFMA_PRICED or r["bytes"] <= 0 or r["flops"] / max(r["bytes"], 1.0) >= RIDGE
                 fp32 = r["shape"].get("dtype") == "fp32"
                 if mfma:
                     peak = PEAK_FP32_MFMA_TFLOPS if fp32 else PEAK_BF16_TFLOPS
                     ach = r["flops"] / avg_s / 1e12
                     row.update(bound="mfma", achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                                flops_per_launch=r["flops"])
+                    if r["bytes"] > 0 and r["flops"] / r["bytes"] < RIDGE:      # below the ridge by its own bytes
+                        row.update(bytes_per_launch=r["bytes"], hbm_frac=round(r["bytes"] / avg_s / 1e9 / PEAK_HBM_GBS, 4))
                 else:
                     ach = r["bytes"] / avg_s / 1e9
                     row.update(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
@@ -228,5 +234,7 @@ def format_table(tab, top=40):
         ach = f"{r['achieved']:.0f} {r['unit']}" if "achieved" in r else ""
         frac = f"{r['frac']:.3f}" if "frac" in r else ""
         shape = " ".join(f"{k}={v}" for k, v in r["shape"].items())
+        if "hbm_frac" in r:
+            shape += f"  (by its {r['bytes_per_launch'] / 1e6:.0f} MB of saved activations: {r['hbm_frac']:.3f} of HBM)"
         lines.append(f"{r['entry'][4:]:28s} {r['launches_per_step']:6.1f} {r['ms_per_step']:8.3f} {r['avg_us']:8.1f} {ach:>14s} {frac:>6s}  {shape}")
     return "\n".join(lines)

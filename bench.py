@@ -251,15 +251,17 @@ def choose_launch(w, world, dev, backend, n=4):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t)
         return el / n * 1e3
+    from dtt_amd import ops
     tg = timed(w["step"])
+    _eager_pack_plan()                         # the eager step as it would run: its packs from one launch too
     te = timed(w["eager_step"])
     w["calibration"] = {"graph_ms": round(tg, 2), "eager_ms": round(te, 2)}
     if te < 0.98 * tg:
         w["step"] = w["eager_step"]
-        _eager_pack_plan()
         w["mode"] = (f"eager issue, weight gradients and lip encoder on side streams (calibration on this box: eager "
                      f"{te:.1f} ms, graph replay {tg:.1f} ms per step)")
     else:
+        ops.weight_plan(False)                 # (the recorded step keeps its own plan's buffers)
         w["graph_step"].rearm()
         w["mode"] += f" (calibration on this box: graph replay {tg:.1f} ms, eager {te:.1f} ms per step)"
 
@@ -458,6 +460,9 @@ def step_roofline(w, cfg, B, precision, workload):
     lanes = (ops._WGRAD_LANE[0], ops._VIDEO_LANE[0])
     ops.wgrad_lane(False)
     ops.video_lane(False)
+    plan_was = ops._PLAN.enabled
+    if not plan_was:
+        _eager_pack_plan()                     # (a recorded step was timed: the eager probe packs from one launch as well)
     try:
         for i in range(2):
             step(i)
@@ -470,6 +475,8 @@ def step_roofline(w, cfg, B, precision, workload):
     finally:
         ops.wgrad_lane(lanes[0])
         ops.video_lane(lanes[1])
+        if not plan_was:
+            ops.weight_plan(False)
     rows = tab["rows"]
     for r in rows:
         r["share_of_step"] = round(r["ms_per_step"] / tab["span_ms_per_step"], 4)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-kernel time of the LAST K training steps of a rocprofv3 --kernel-trace CSV (warm-up, MIOpen's find step
-and the roofline probes excluded): steps are delimited by adamw_update_kernel, which runs once per step.
+"""Per-kernel time of the LAST K training steps of a rocprofv3 --kernel-trace CSV: steps are delimited by
+adamw_update_kernel, which runs once per step.  Of a bench.py run these are the eagerly issued one-stream steps of its
+roofline probe (a HIP-graph replay's kernels carry no per-step order a trace could be cut at).
 
     python tools/trace_steps.py <kernel_trace.csv> [K] [rows]
 """

@@ -206,8 +206,10 @@ class CallTimer:
             row = dict(entry=r["entry"], shape=r["shape"], launches_per_step=round(n / nsteps, 2),
                        ms_per_step=round(tot / nsteps, 4), avg_us=round(avg_s * 1e6, 1))
             if r["flops"] > 0 or r["bytes"] > 0:
-                mfma = r["entry"] in MFMA_PRICED or r["bytes"] <= 0 or r["flops"] / max(r["bytes"], 1.0) >= RIDGE
                 fp32 = r["shape"].get("dtype") == "fp32"
+                # (the ridge of the type the entry computes in: the exact-fp32 DFT products sit far above theirs)
+                ridge = RIDGE * PEAK_FP32_MFMA_TFLOPS / PEAK_BF16_TFLOPS if fp32 else RIDGE
+                mfma = r["entry"] in MFMA_PRICED or r["bytes"] <= 0 or r["flops"] / max(r["bytes"], 1.0) >= ridge
                 if mfma:
                     peak = PEAK_FP32_MFMA_TFLOPS if fp32 else PEAK_BF16_TFLOPS
                     ach = r["flops"] / avg_s / 1e12

@@ -998,6 +998,9 @@ def _pack_pair(tag, wa, wb, dt, fwd):
                   (shape, dt, lambda out: [(out[0], vw(wa)), (out[1], vw(wb))]))
 
 
+_DXN_T = os.environ.get("DTT_DXN_T", "1") != "0"      # 0: dxn = dG W_ih with W_ih as stored (A/B switch)
+
+
 def _unblock(t, W, N, L, heads):
     """blocked [2][nblk][L][W/H..] activation layout of the fused LSTM kernels -> row-major [R][2][W]
     (debug / transition helper: index q = lh*16 + r of the last axis is local sequence
@@ -1258,6 +1261,7 @@ class DualPathRNN(torch.autograd.Function):
         gemm_raw(A=y, B=fcw, C=out, bias=fc_b, R=res, M=R, N=Cp, K=2 * H, a_ms=2 * H, a_ks=1, b_ks=1, b_ns=2 * H,
                  c_ms=Cp, c_ns=1, r_ms=Cp, r_ns=1, dtype=d, bias_mode=1)
         ctx.save_for_backward(x, gamma, xn, gstats, wih, w_hh, w_hh_r, y, gates, cst, fcw)
+        ctx.w_ih_pair = (w_ih, w_ih_r)                 # (parameters: sources of the transposed pack in backward)
         ctx.cfg = (heads, along_f, geo, gs, blocked, geom, rs)
         # along_f: memory order is [B,T,F,C]; the view below is the reference's merge_heads quirk
         return out.view(B, Fq, T, Cc)
@@ -1330,8 +1334,18 @@ class DualPathRNN(torch.autograd.Function):
         if dbias is None:           # (on the launch stream: each half is returned for two parameters, which autograd clones)
             dbias = colsum(dG, R, 2 * G4)
         dxn = _empty((nslab, L, Cc), dt, dev)
-        gemm_raw(A=dG, B=wih, C=dxn, M=R, N=Cp, K=2 * G4, a_ms=2 * G4, a_ks=1, b_ks=Cp, b_ns=1, c_ms=Cp, c_ns=1,
-                 dtype=d)
+        if _DXN_T and d == 1 and Cp % 8 == 0 and Cp >= 256:
+            # W_ih transposed, [Cp][8H]: both operands k-contiguous, which is what the 256 x 256 LDS-DMA tiles take
+            # (33 280 x 256 x 4096: 125 us against 154 for the 128 x 128 tiles of the n-contiguous form; in the step,
+            # beside the weight-gradient products on their side stream, -0.08 ms: DTT_DXN_T=0 is the A/B switch)
+            w_ih, w_ih_r = ctx.w_ih_pair
+            wihT = packed(_wkey("wihT", dt, w_ih, w_ih_r), lambda: wih.t().contiguous(),
+                          ((Cp, 2 * G4), dt, lambda out: [(out[:, :G4], w_ih.t()), (out[:, G4:], w_ih_r.t())]))
+            gemm_raw(A=dG, B=wihT, C=dxn, M=R, N=Cp, K=2 * G4, a_ms=2 * G4, a_ks=1, b_ks=1, b_ns=2 * G4, c_ms=Cp, c_ns=1,
+                     dtype=d)
+        else:
+            gemm_raw(A=dG, B=wih, C=dxn, M=R, N=Cp, K=2 * G4, a_ms=2 * G4, a_ks=1, b_ks=Cp, b_ns=1, c_ms=Cp, c_ns=1,
+                     dtype=d)
         dx = torch.empty_like(x)
         pgb = _empty((nslab, Cc, 2), F32, dev)
         check(lib().dtt_gn_bwd(ptr(x), ptr(dxn), ptr(dout), ptr(gamma), ptr(gstats), ptr(dx), ptr(pgb), *geo, d,

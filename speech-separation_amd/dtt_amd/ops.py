@@ -81,14 +81,29 @@ def wgrad_lane(enabled=True):
     _WGRAD_LANE[0] = bool(enabled)
 
 
-class _lane:
-    """with _lane(dev, tensors to keep alive...): launches inside go to the device's side stream."""
+def _lane_ok(*params):
+    """May the gradients of these forward inputs be produced on the side stream?  Only when nothing inside the
+    backward pass reads them on the launch stream: every one a leaf (a slice or view of a parameter has a backward
+    node of its own, which would read the gradient unsynchronised) whose .grad is still empty (AccumulateGrad then
+    just keeps the tensor; with a .grad in place -- gradient accumulation over micro-batches, zero_grad(set_to_none=
+    False) -- it adds on the launch stream).  Anything else computes on the launch stream."""
+    for p in params:
+        if p is None or not torch.is_tensor(p) or not p.requires_grad:
+            continue
+        if p.grad_fn is not None or p.grad is not None:
+            return False
+    return True
 
-    def __init__(self, dev, *keep):
-        self.dev, self.keep, self.ctx = dev, keep, None
+
+class _lane:
+    """with _lane(dev, tensors to keep alive..., on=...): launches inside go to the device's side stream (on=False:
+    they stay on the launch stream, see _lane_ok)."""
+
+    def __init__(self, dev, *keep, on=True):
+        self.dev, self.keep, self.ctx, self.on = dev, keep, None, on
 
     def __enter__(self):
-        if not _WGRAD_LANE[0] or self.dev.type != "cuda":
+        if not self.on or not _WGRAD_LANE[0] or self.dev.type != "cuda":
             return self
         ln = _LANES.setdefault(_dev_index(self.dev), _Lane())
         if ln.stream is None:
@@ -247,13 +262,13 @@ def conv_gemm_transposed(x, wp, bias, out, geom, res00=None):
             gemm_raw(**kw)
 
 
-def conv_wgrad(p_side, q_side, geom, M, N):
+def conv_wgrad(p_side, q_side, geom, M, N, on=True):
     """dWp[m][tap][n] = sum_p P[p][m] * Q[src(p,tap)][n]; geom: cFo/cTo = P grid, cFi/cTi = Q grid."""
     P = geom["cB"] * geom["cFo"] * geom["cTo"]
     dwp = _zeros_f32((M, 9, N,), p_side.device)
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * 9
     splitk = int(max(1, min(512, round(768 / tiles), (P + 255) // 256)))     # ~3 workgroups per CU: atomic tail
-    with _lane(p_side.device, p_side, q_side):
+    with _lane(p_side.device, p_side, q_side, on=on):
         gemm_raw(A=p_side, B=q_side, C=dwp, M=M, N=N, K=P, batch=9, splitk=splitk, a_ms=1, a_ks=M, a_bs=0,
                  b_ks=N, b_ns=1, b_bs=0, c_ms=9 * N, c_ns=1, c_bs=N, dtype=_dt(p_side), atomic=1, out_f32=1,
                  b_mode=1, **geom)
@@ -647,13 +662,14 @@ def _conv_backward(kind, x, w, dy, need_dx, tile=True, phases=False, res=None, r
     gradient's epilogue (GradSlot)."""
     B, Fi, Ti, Ci = x.shape
     Co = dy.shape[3]
+    on = _lane_ok(w)                               # the weight gradient may leave the launch stream
     _, _, _, gd, gw = _conv_geoms(kind, B, Fi, Ti, Ci, Co)
     if kind == "s1" and tile and _fast3(dy, Ci) and _fast3(x, Co):
         if x.dtype == torch.bfloat16:
             need = lib().dtt_conv3x3_wgrad_ws_bytes(B, Fi, Ti, Ci, Co)
             if need > 0:        # partial sums through a workspace + one sum launch instead of fp32 atomics;
                 dw = _empty((Co, Ci, 3, 3), F32, x.device)      # the sum writes the parameter's own layout
-                with _lane(x.device, dy, x):
+                with _lane(x.device, dy, x, on=on):
                     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
                     check(lib().dtt_conv3x3_wgrad_ws_param(ptr(dy), ptr(x), ptr(dw), ptr(ws), C.c_int64(need), B, Fi, Ti,
                                                            Ci, Co, 1, stream_ptr()), "dtt_conv3x3_wgrad_ws_param")
@@ -661,22 +677,22 @@ def _conv_backward(kind, x, w, dy, need_dx, tile=True, phases=False, res=None, r
                 return dx, dw
             else:
                 dwp = _zeros_f32((Co, 9, Ci,), x.device)
-                with _lane(x.device, dy, x):
+                with _lane(x.device, dy, x, on=on):
                     check(lib().dtt_conv3x3_wgrad(ptr(dy), ptr(x), ptr(dwp), B, Fi, Ti, Ci, Co, 1, stream_ptr()),
                           "dtt_conv3x3_wgrad")
         else:
-            dwp = conv_wgrad(dy, x, gw, Co, Ci)
-        with _lane(x.device, dwp):
+            dwp = conv_wgrad(dy, x, gw, Co, Ci, on=on)
+        with _lane(x.device, dwp, on=on):
             dw = dwp.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
         dx = conv3x3_s1(dy, _pack_dgrad(w, kind, x.dtype), None, res=res)[0] if need_dx else None
         return dx, dw
     if kind == "up":
-        dwp = conv_wgrad(x, dy, gw, Ci, Co)                      # [Ci][9][Co]
+        dwp = conv_wgrad(x, dy, gw, Ci, Co, on=on)                      # [Ci][9][Co]
         dw = dwp.view(Ci, 3, 3, Co).permute(0, 3, 1, 2)
     else:
-        dwp = conv_wgrad(dy, x, gw, Co, Ci)                      # [Co][9][Ci]
+        dwp = conv_wgrad(dy, x, gw, Co, Ci, on=on)                      # [Co][9][Ci]
         dw = dwp.view(Co, 3, 3, Ci).permute(0, 3, 1, 2)
-    with _lane(x.device, dwp):
+    with _lane(x.device, dwp, on=on):
         dw = dw.contiguous()
     dx = None
     if need_dx:
@@ -733,6 +749,7 @@ class ConvAdd(torch.autograd.Function):
             y = _empty((B, Fi, Ti, Co), x.dtype, x.device)
             conv_gemm(x, _pack_fwd(w, "s1", x.dtype), b, y, gf, res=h)
         ctx.save_for_backward(x, w)
+        ctx.bias_param = b
         return y
 
     @staticmethod
@@ -741,7 +758,7 @@ class ConvAdd(torch.autograd.Function):
         dy = dy.contiguous()
         dx, dw = _conv_backward("s1", x, w, dy, ctx.needs_input_grad[0])
         Co = dy.shape[3]
-        with _lane(dy.device, dy):
+        with _lane(dy.device, dy, on=_lane_ok(ctx.bias_param)):
             db = colsum(dy, dy.numel() // Co, Co)
         if ctx.slot is not None and dx is not None:
             ctx.slot.put(dx)                 # x's other consumer (conv1[0]) adds it inside its data-gradient conv
@@ -843,7 +860,7 @@ class Conv1x1s2(torch.autograd.Function):
             dyc = dyc.contiguous()
         P = B * g["cFo"] * g["cTo"]
         dwp = _zeros_f32((Co, Ci), xc.device)
-        with _lane(xc.device, dyc, xc):
+        with _lane(xc.device, dyc, xc, on=_lane_ok(w)):
             gemm_raw(A=dyc, B=xc, C=dwp, M=Co, N=Ci, K=P, splitk=_splitk(Co, Ci, P), a_ms=1, a_ks=Co, b_ks=Ci, b_ns=1, c_ms=Ci,
                      c_ns=1, dtype=_dt(xc), atomic=1, out_f32=1, b_mode=1, **g)
         dx = None
@@ -894,7 +911,7 @@ class FrontConv(torch.autograd.Function):
         gemm_raw(A=x5p, B=wp, C=y, M=NF * Ho * Wo, N=Co, K=KH * 64, a_ms=0, a_ks=1, b_ks=1, b_ns=KH * 64, c_ms=Co, c_ns=1,
                  dtype=_dt(x5p), a_mode=1, **geom)
         ctx.save_for_backward(x5p)
-        ctx.geom, ctx.wshape = geom, tuple(w.shape)
+        ctx.geom, ctx.wshape, ctx.lane_params = geom, tuple(w.shape), (w,)
         return y
 
     @staticmethod
@@ -906,7 +923,7 @@ class FrontConv(torch.autograd.Function):
         P, N = g["cB"] * g["cFo"] * g["cTo"], KH * 64
         dwp = _zeros_f32((Co, N), dy.device)
         tiles = -(-Co // 64) * -(-N // 128)
-        with _lane(dy.device, dy, x5p, dwp):
+        with _lane(dy.device, dy, x5p, dwp, on=_lane_ok(*ctx.lane_params)):
             gemm_raw(A=dy, B=x5p, C=dwp, M=Co, N=N, K=P, splitk=max(1, min(256, 512 // tiles)), a_ms=1, a_ks=Co, b_ks=N,
                      b_ns=1, c_ms=N, c_ns=1, dtype=_dt(dy), atomic=1, out_f32=1, b_mode=1, **g)
             dw = dwp.view(Co, KH, 8, 8)[:, :, :KWr, :kt].permute(0, 3, 1, 2).unsqueeze(1).contiguous()
@@ -938,6 +955,7 @@ class TDF(torch.autograd.Function):
                  b_ns=1, b_bs=J * N, c_ms=N, c_ns=1, c_bs=Fq * N, r_ms=N, r_ns=1, r_bs=Fq * N, dtype=_dt(x),
                  bias_mode=2)
         ctx.save_for_backward(x, hid, w1p, w2p)
+        ctx.lane_params = (w1, b1, w2, b2)
         return out
 
     @staticmethod
@@ -955,7 +973,7 @@ class TDF(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw2, dw1, db2, db1 = _zeros_f32((Fq, J,), dev), _zeros_f32((J, Fq,), dev), _zeros_f32((Fq,), dev), _zeros_f32((J,), dev)
         ones = torch.ones(N, dtype=x.dtype, device=dev)
-        with _lane(dev, dout, hid, dhid, x, ones):
+        with _lane(dev, dout, hid, dhid, x, ones, on=_lane_ok(*ctx.lane_params)):
             gemm_raw(A=dout, B=hid, C=dw2, M=Fq, N=J, K=N, batch=B, splitk=_splitk(Fq, J, N, B), a_ms=N, a_ks=1, a_bs=Fq * N,
                      b_ks=1, b_ns=N, b_bs=J * N, c_ms=J, c_ns=1, c_bs=0, dtype=d, atomic=1, out_f32=1)
             gemm_raw(A=dhid, B=x, C=dw1, M=J, N=Fq, K=N, batch=B, splitk=_splitk(J, Fq, N, B), a_ms=N, a_ks=1, a_bs=J * N,
@@ -1262,6 +1280,7 @@ class DualPathRNN(torch.autograd.Function):
                  c_ms=Cp, c_ns=1, r_ms=Cp, r_ns=1, dtype=d, bias_mode=1)
         ctx.save_for_backward(x, gamma, xn, gstats, wih, w_hh, w_hh_r, y, gates, cst, fcw)
         ctx.w_ih_pair = (w_ih, w_ih_r)                 # (parameters: sources of the transposed pack in backward)
+        ctx.lane_params = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, fc_w, fc_b)
         ctx.cfg = (heads, along_f, geo, gs, blocked, geom, rs)
         # along_f: memory order is [B,T,F,C]; the view below is the reference's merge_heads quirk
         return out.view(B, Fq, T, Cc)
@@ -1283,7 +1302,8 @@ class DualPathRNN(torch.autograd.Function):
         gemm_raw(A=dout, B=fcw, C=dy, M=R, N=2 * H, K=Cp, a_ms=Cp, a_ks=1, b_ks=2 * H, b_ns=1, c_ms=2 * H, c_ns=1,
                  dtype=d)
         dfcw = _zeros_f32((Cp, 2 * H,), dev)
-        with _lane(dev, dout, y):
+        lane_on = _lane_ok(*ctx.lane_params)
+        with _lane(dev, dout, y, on=lane_on):
             gemm_raw(A=dout, B=y, C=dfcw, M=Cp, N=2 * H, K=R, splitk=_splitk(Cp, 2 * H, R), a_ms=1, a_ks=Cp, b_ks=2 * H,
                      b_ns=1, c_ms=2 * H, c_ns=1, dtype=d, atomic=1, out_f32=1)
             dfcb = colsum(dout, R, Cp)
@@ -1324,7 +1344,7 @@ class DualPathRNN(torch.autograd.Function):
         G4 = 4 * H
         dwhh = [_zeros_f32((G4, H,), dev), _zeros_f32((G4, H,), dev)]
         dwih = _zeros_f32((2 * G4, Cp,), dev)
-        with _lane(dev, dG, y, xn):
+        with _lane(dev, dG, y, xn, on=lane_on):
             for di, (shift, edge) in enumerate(((-heads, 0), (heads, L - 1))):
                 gemm_raw(A=dG[:, di], B=y[:, di * H:], C=dwhh[di], M=G4, N=H, K=R, splitk=_splitk(G4, H, R), a_ms=1, a_ks=2 * G4,
                          b_ks=2 * H, b_ns=1, c_ms=H, c_ns=1, dtype=d, atomic=1, out_f32=1, b_mode=2, sh_shift=shift,
@@ -1621,7 +1641,7 @@ def _linear_fwd(x2d, w, b, out2d, res=None):
     gemm_raw(**kw)
 
 
-def _linear_bwd(x2d, w, dy2d, need_dx=True):
+def _linear_bwd(x2d, w, dy2d, need_dx=True, on=True):
     R, K = x2d.shape
     N = w.shape[0]
     d = _dt(x2d)
@@ -1630,7 +1650,7 @@ def _linear_bwd(x2d, w, dy2d, need_dx=True):
         dx = torch.empty_like(x2d)
         gemm_raw(A=dy2d, B=w, C=dx, M=R, N=K, K=N, a_ms=N, a_ks=1, b_ks=K, b_ns=1, c_ms=K, c_ns=1, dtype=d)
     dw = _zeros_f32((N, K,), x2d.device)
-    with _lane(x2d.device, dy2d, x2d):
+    with _lane(x2d.device, dy2d, x2d, on=on):
         gemm_raw(A=dy2d, B=x2d, C=dw, M=N, N=K, K=R, splitk=_splitk(N, K, R), a_ms=1, a_ks=N, b_ks=K,
                  b_ns=1, c_ms=K, c_ns=1, dtype=d, atomic=1, out_f32=1)
     return dx, dw
@@ -1647,7 +1667,7 @@ class Conv1x1(torch.autograd.Function):
         y = _empty(x.shape[:-1] + (Co,), x.dtype, x.device)
         _linear_fwd(x.reshape(-1, Ci), wp, b, y.view(-1, Co))
         ctx.save_for_backward(x, wp)
-        ctx.wshape = w.shape
+        ctx.wshape, ctx.lane_params = w.shape, (w,)
         return y
 
     @staticmethod
@@ -1655,7 +1675,7 @@ class Conv1x1(torch.autograd.Function):
         x, wp = ctx.saved_tensors
         dy = dy.contiguous()
         Co, Ci = wp.shape
-        dx, dw = _linear_bwd(x.reshape(-1, Ci), wp, dy.view(-1, Co), ctx.needs_input_grad[0])
+        dx, dw = _linear_bwd(x.reshape(-1, Ci), wp, dy.view(-1, Co), ctx.needs_input_grad[0], on=_lane_ok(*ctx.lane_params))
         db = colsum(dy, dy.numel() // Co, Co)
         return (dx.view_as(x) if dx is not None else None), dw.view(ctx.wshape), db
 
@@ -1674,7 +1694,7 @@ class Conv1x1NormGelu(torch.autograd.Function):
         stats = in_stats(y)
         z = in_gelu_fwd(y, stats, Fq, T)
         ctx.save_for_backward(x, wp, y, stats)
-        ctx.wshape = w.shape
+        ctx.wshape, ctx.lane_params = w.shape, (w,)
         return z
 
     @staticmethod
@@ -1682,7 +1702,7 @@ class Conv1x1NormGelu(torch.autograd.Function):
         x, wp, y, stats = ctx.saved_tensors
         Co, Ci = wp.shape
         dy = in_gelu_bwd(y, dz.contiguous(), stats)
-        dx, dw = _linear_bwd(x.view(-1, Ci), wp, dy.view(-1, Co), ctx.needs_input_grad[0])
+        dx, dw = _linear_bwd(x.view(-1, Ci), wp, dy.view(-1, Co), ctx.needs_input_grad[0], on=_lane_ok(*ctx.lane_params))
         db = _zeros_f32((Co,), x.device)       # bias ahead of InstanceNorm: exactly zero
         return (dx.view_as(x) if dx is not None else None), dw.view(ctx.wshape), db
 
@@ -2001,7 +2021,7 @@ class Linear(torch.autograd.Function):
         gemm_raw(**kw)
         ctx.save_for_backward(x2, wt, y if sigmoid else None)
         ctx.has_bias = b is not None
-        ctx.xshape = x.shape
+        ctx.xshape, ctx.lane_params = x.shape, (w,)
         return y.view(x.shape[:-1] + (wt.shape[0],))
 
     @staticmethod
@@ -2011,7 +2031,9 @@ class Linear(torch.autograd.Function):
         if y is not None:
             dy2 = dy2 * (y * (1.0 - y))
         dy2 = dy2.contiguous()
-        dx, dw = _linear_bwd(x2, wt, dy2, ctx.needs_input_grad[0])
+        # (a weight that is a slice of a parameter -- the q / k / v thirds of in_proj_weight -- has a backward node that
+        # reads dw on the launch stream: no side stream for it)
+        dx, dw = _linear_bwd(x2, wt, dy2, ctx.needs_input_grad[0], on=_lane_ok(*ctx.lane_params))
         db = colsum(dy2, dy2.shape[0], dy2.shape[1]) if ctx.has_bias else None
         return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None
 

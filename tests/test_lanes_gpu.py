@@ -68,9 +68,24 @@ def test_side_streams_change_nothing_but_the_schedule(precision, tol):
     atol = 2e-6 if precision == "fp32" else 2e-3
     bad = [k for k in g0 if not grad_close(g1[k], g0[k], max(10 * tol, 20 * rel_err(g2[k], g0[k])), atol=atol)]
     assert not bad, [(k, rel_err(g1[k], g0[k]), rel_err(g2[k], g0[k]), float(g0[k].abs().max())) for k in bad[:5]]
-    for k in p0:                                           # three updates later: within a few times the noise floor
-        e, floor = rel_err(p1[k], p0[k]), rel_err(p2[k], p0[k])
-        assert e < max(tol, 20 * floor), (k, e, floor)
+    # three updates later: within a few times the noise floor.  (The one-stream step repeats itself bit for bit, so
+    # the floor can be 0; a different order of the split-K atomics is a rounding-level change of the first update that
+    # bf16 activations re-round into percent-level changes of small gradients deep in the lip encoder, which Adam's
+    # normalisation passes on undamped: seen 3-4 % on one BatchNorm bias, hence 3 x the layer tolerance.)
+    # Elements whose gradient is rounding noise (mathematically zero: biases ahead of a normalisation, the key third
+    # of in_proj_bias under a softmax) walk wherever Adam's normalisation takes that noise: only elements with a
+    # first-step gradient of at least 1 % of their tensor's largest are compared.
+    checked = 0
+    for k in p0:
+        if k not in g0:
+            continue
+        m = g0[k].abs() >= 1e-2 * g0[k].abs().max().clamp(min=1e-30)
+        if int(m.sum()) == 0:
+            continue
+        e, floor = rel_err(p1[k][m], p0[k][m]), rel_err(p2[k][m], p0[k][m])
+        assert e < max(3 * tol, 20 * floor), (k, e, floor)
+        checked += 1
+    assert checked > 100
 
 
 def test_side_streams_survive_a_consumer_inside_backward():
@@ -145,3 +160,40 @@ def test_graph_step_rearms_after_eager_steps():
     assert want[0] > want[-1]                                    # the steps train
     for i, (a, b) in enumerate(zip(got, want)):                  # (later steps drift like any two runs: test_graph_gpu.py)
         assert abs(a - b) < (1e-5 if i < 2 else 2e-2) * abs(b), (got, want)
+
+
+def test_side_streams_stand_aside_for_accumulation_and_parameter_slices():
+    """Gradients that something reads on the launch stream INSIDE the backward pass stay off the side stream
+    (ops._lane_ok): a second backward into existing .grad tensors (AccumulateGrad adds), and weights that are slices
+    of a parameter (the q / k / v thirds of in_proj_weight: SliceBackward copies).  Two accumulated micro-batches with
+    side streams on equal the same with side streams off."""
+    import dtt_amd
+    from dtt_amd import ops
+    assert not ops._lane_ok(torch.nn.Parameter(torch.zeros(4, 4, device=DEV))[:2])          # a slice: has a grad_fn
+    p = torch.nn.Parameter(torch.zeros(4, device=DEV))
+    assert ops._lane_ok(p, None)
+    p.grad = torch.zeros_like(p)
+    assert not ops._lane_ok(p)
+
+    def run(lanes):
+        model = _model(9, "fp32")
+        keep = (ops._WGRAD_LANE[0], ops._VIDEO_LANE[0])
+        ops.wgrad_lane(lanes)
+        ops.video_lane(lanes)
+        try:
+            crit = dtt_amd.PITLossWrapper(dtt_amd.DTTNetLoss())
+            video = synth_video(2, 4, seed=91).to(DEV)
+            for i in range(2):                                    # no zeroing in between: the second pass accumulates
+                b = to_dev(make_batch(2, 800, 64, 16, seed=70 + i), DEV)
+                b.update(model(video=video, **b))
+                b.update(crit(**b))
+                b["loss"].backward()
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            ops.wgrad_lane(keep[0])
+            ops.video_lane(keep[1])
+    g0, g1, g2 = run(False), run(True), run(False)
+    bad = [k for k in g0 if not grad_close(g1[k], g0[k], max(2e-3, 20 * rel_err(g2[k], g0[k])), atol=2e-6)]
+    assert not bad, [(k, rel_err(g1[k], g0[k]), rel_err(g2[k], g0[k])) for k in bad[:5]]
+    assert "fusion.cross_attn.in_proj_weight" in g0

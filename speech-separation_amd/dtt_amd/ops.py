@@ -62,7 +62,7 @@ def reset_zero_arena():
 # --------------------------------------------------------------------------- #
 class _Lane:
     def __init__(self):
-        self.stream, self.pending, self.keep, self.cb, self.fork = None, False, [], False, None
+        self.stream, self.pending, self.keep, self.cb, self.fork = None, False, [], -1, None   # cb: task id with a join queued
 
 
 _LANES = {}
@@ -118,10 +118,13 @@ class _lane:
             ln.stream.wait_stream(torch.cuda.current_stream(self.dev))
         ln.keep.extend(self.keep)
         ln.pending = True
-        if not ln.cb:
-            try:                                   # joined when the backward pass that issued the work ends
+        # joined when the backward pass that issued the work ends: one callback per pass, told apart by autograd's task
+        # id (a flag alone would stay set after a pass that raised, and the next pass would end unjoined)
+        task = torch._C._current_graph_task_id()
+        if task >= 0 and ln.cb != task:
+            try:
                 torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_lane)
-                ln.cb = True
+                ln.cb = task
             except RuntimeError:                   # not inside a backward pass: the caller joins
                 pass
         self.ctx = torch.cuda.stream(ln.stream)
@@ -141,7 +144,6 @@ def join_wgrad_lane():
             torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(ln.stream)
             ln.keep.clear()
             ln.pending = False
-        ln.cb = False
 
 
 _VIDEO_LANE = [os.environ.get("DTT_VIDEO_LANE", "1") == "1"]

@@ -197,3 +197,47 @@ def test_side_streams_stand_aside_for_accumulation_and_parameter_slices():
     bad = [k for k in g0 if not grad_close(g1[k], g0[k], max(2e-3, 20 * rel_err(g2[k], g0[k])), atol=2e-6)]
     assert not bad, [(k, rel_err(g1[k], g0[k]), rel_err(g2[k], g0[k])) for k in bad[:5]]
     assert "fusion.cross_attn.in_proj_weight" in g0
+
+
+def test_a_backward_pass_that_raised_does_not_leave_the_next_one_unjoined():
+    """The join is queued once per autograd task (by task id): after a pass that raised before its final callbacks ran,
+    the next pass queues its own and ends joined."""
+    from dtt_amd import ops
+    keep = ops._WGRAD_LANE[0]
+    ops.wgrad_lane(True)
+    try:
+        w = torch.nn.Parameter(torch.randn(64, 32, device=DEV))
+        x = torch.randn(256, 32, device=DEV)
+
+        class Boom(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError("boom")
+        y = ops.Linear.apply(Boom.apply(x.requires_grad_()), w, None, False)
+        with pytest.raises(RuntimeError):
+            y.sum().backward()                  # Linear's backward forked, Boom raised: no final callback ran
+        ops.join_wgrad_lane()                   # (what the next optimizer step / loss wrapper does anyway)
+        w.grad = None
+        y = ops.Linear.apply(x.detach(), w, None, False)
+        y.sum().backward()
+        ln = ops._LANES[torch.cuda.current_device()]
+        assert not ln.pending                   # this pass queued its own join and it ran
+        torch.cuda.synchronize()
+        want = torch.ones(256, 64, device=DEV).t() @ x.detach()
+        assert rel_err(w.grad, want) < 1e-4
+        # and without the explicit join in between
+        y = ops.Linear.apply(Boom.apply(x), w, None, False)
+        with pytest.raises(RuntimeError):
+            y.sum().backward()
+        w.grad = None
+        ops.Linear.apply(x.detach(), w, None, False).sum().backward()
+        assert not ln.pending
+        torch.cuda.synchronize()
+        assert rel_err(w.grad, want) < 1e-4
+    finally:
+        ops.join_wgrad_lane()
+        ops.wgrad_lane(keep)

@@ -215,7 +215,7 @@ class CallTimer:
                     ach = r["flops"] / avg_s / 1e12
                     row.update(bound="mfma", achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                                flops_per_launch=r["flops"])
-                    if r["bytes"] > 0 and r["flops"] / r["bytes"] < RIDGE:      # below the ridge by its own bytes
+                    if r["bytes"] > 0 and r["flops"] / r["bytes"] < ridge:      # below the ridge by its own bytes
                         row.update(bytes_per_launch=r["bytes"], hbm_frac=round(r["bytes"] / avg_s / 1e9 / PEAK_HBM_GBS, 4))
                 else:
                     ach = r["bytes"] / avg_s / 1e9

@@ -65,8 +65,11 @@ def test_side_streams_change_nothing_but_the_schedule(precision, tol):
         assert abs(a - b) <= tol * abs(a), (l0, l1)
     assert set(g0) == set(g1) and len(g0) > 100
     # (grad_close: gradients that are mathematically zero -- a bias ahead of a normalisation -- hold rounding noise only)
-    atol = 2e-6 if precision == "fp32" else 2e-3
-    bad = [k for k in g0 if not grad_close(g1[k], g0[k], max(10 * tol, 20 * rel_err(g2[k], g0[k])), atol=atol)]
+    atol = 1e-8
+    # first-step gradients (same weights, same forward): the side streams change the order of split-K atomics and
+    # nothing else -- measured 2e-7 in both precisions (tools/lanes_grad_agreement.py), so a bound of 2e-5 is a sharp
+    # detector of a gradient read before its side-stream kernel wrote it
+    bad = [k for k in g0 if not grad_close(g1[k], g0[k], max(2e-5, 20 * rel_err(g2[k], g0[k])), atol=atol)]
     assert not bad, [(k, rel_err(g1[k], g0[k]), rel_err(g2[k], g0[k]), float(g0[k].abs().max())) for k in bad[:5]]
     # three updates later: within a few times the noise floor.  (The one-stream step repeats itself bit for bit, so
     # the floor can be 0; a different order of the split-K atomics is a rounding-level change of the first update that

@@ -244,3 +244,42 @@ def test_a_backward_pass_that_raised_does_not_leave_the_next_one_unjoined():
     finally:
         ops.join_wgrad_lane()
         ops.wgrad_lane(keep)
+
+
+def test_side_streams_at_the_bench_configuration():
+    """The default bench workload (cfg4: x-attn 60M with the lip encoder, B = 16, bf16), eagerly issued as bench.py
+    times it: gradients of one step with the side streams on against the one-stream step on the same weights, every
+    parameter, to the order-of-atomics floor.  At this size the side streams really run beside the launch stream (5 ms
+    of overlap per step), which the tiny model above cannot promise."""
+    from dtt_amd import ops
+    from test_graph_gpu import _bench_workload
+    w = _bench_workload("0")
+    model = w["model"]
+    for grp in w["opt"].param_groups:
+        grp["lr"], grp["weight_decay"] = 0.0, 0.0              # the weights stay put
+
+    def grads(lanes):
+        keep = (ops._WGRAD_LANE[0], ops._VIDEO_LANE[0])
+        ops.wgrad_lane(lanes)
+        ops.video_lane(lanes)
+        try:
+            w["eager_step"](0)
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            ops.wgrad_lane(keep[0])
+            ops.video_lane(keep[1])
+    try:
+        grads(False)                                           # (records the pack plan, warms the allocator)
+        g0, g1, g2, g3 = grads(False), grads(True), grads(False), grads(True)
+    finally:
+        ops.weight_plan(False)
+        ops.reset_zero_arena()
+    assert len(g0) > 300
+    bad = []
+    for k in g0:
+        floor = rel_err(g2[k], g0[k])
+        for g in (g1, g3):
+            if not grad_close(g[k], g0[k], max(1e-4, 20 * floor), atol=1e-8):
+                bad.append((k, rel_err(g[k], g0[k]), floor, float(g0[k].abs().max())))
+    assert not bad, bad[:6]

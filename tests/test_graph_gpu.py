@@ -200,6 +200,8 @@ def test_bench_graph_gradients_match_eager_after_a_host_sync():
         ref = p.grad.float()
         scale = float(ref.norm()) + 1e-6
         eb, ea = float((gb.float() - ref).norm()) / scale, float((ga.float() - ref).norm()) / scale
-        if max(eb, ea) > 3e-2 and scale > 1e-4:
+        # (same weights, same kernels: replay and eager issue differ by the order of split-K atomics only -- measured
+        # 5e-7 at worst over all parameters -- so 1e-4 is a sharp bound)
+        if max(eb, ea) > 1e-4 and scale > 1e-6:
             worst.append((max(eb, ea), k, eb, ea, scale))
     assert not worst, sorted(worst, reverse=True)[:8]

@@ -283,3 +283,53 @@ def test_side_streams_at_the_bench_configuration():
             if not grad_close(g[k], g0[k], max(1e-4, 20 * floor), atol=1e-8):
                 bad.append((k, rel_err(g[k], g0[k]), floor, float(g0[k].abs().max())))
     assert not bad, bad[:6]
+
+
+def test_pack_plan_at_the_bench_configuration():
+    """Every derived weight tensor of the cfg4 step from the one dtt_multi_pack launch (contiguous casts, tap-major and
+    backwards-walked conv packs, LSTM transposes, the slices of in_proj_weight) against the per-use packs: gradients
+    of a step on the same weights, before and after the weights moved (the plan follows the parameters), every
+    parameter at the atomics floor."""
+    from dtt_amd import ops
+    from test_graph_gpu import _bench_workload
+    w = _bench_workload("0")
+    model = w["model"]
+    for grp in w["opt"].param_groups:
+        grp["lr"], grp["weight_decay"] = 0.0, 0.0
+    keep = (ops._WGRAD_LANE[0], ops._VIDEO_LANE[0])
+    ops.wgrad_lane(False)
+    ops.video_lane(False)
+
+    def grads():
+        w["eager_step"](0)
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    def agree(a, b, floor):
+        return [(k, rel_err(a[k], b[k])) for k in b if not grad_close(a[k], b[k], max(1e-4, 20 * rel_err(floor[k], b[k])), atol=1e-8)]
+    try:
+        assert ops._PLAN.enabled
+        grads()                                                # records the plan
+        assert len(ops._PLAN.pairs) > 150
+        on1 = grads()                                          # refreshed by the one launch
+        orig = [p.detach().clone() for p in model.parameters()]
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.02)
+        on2 = grads()
+        ops.weight_plan(False)
+        off2, off2b = grads(), grads()
+        with torch.no_grad():
+            for p, o in zip(model.parameters(), orig):
+                p.copy_(o)
+        off1, off1b = grads(), grads()
+        bad2, bad1 = agree(on2, off2, off2b), agree(on1, off1, off1b)
+        assert not bad2, ("after the weights moved", bad2[:6])
+        assert not bad1, ("on the first weights", bad1[:6])
+        moved = [k for k in off1 if rel_err(off2[k], off1[k]) > 1e-3]
+        assert len(moved) > 200                                # (the two weight sets really give different gradients)
+    finally:
+        ops.weight_plan(False)
+        ops.reset_zero_arena()
+        ops.wgrad_lane(keep[0])
+        ops.video_lane(keep[1])

@@ -128,7 +128,7 @@ def test_pack_plan_matches_plain_steps():
     assert close(g0, g1) and close(g0, g2) and close(g4, g3)
 
 
-def _bench_workload(mode):
+def _bench_workload(mode, name="xattn60m"):
     import argparse
     import os
     import sys
@@ -137,7 +137,7 @@ def _bench_workload(mode):
     import bench
     from dtt_amd.dist import GradBucketReducer
     args = argparse.Namespace(batch=None, precision="bf16", graph=mode)
-    w = bench.build_workload("xattn60m", args, torch.device("cuda", 0), 0, 1, GradBucketReducer)
+    w = bench.build_workload(name, args, torch.device("cuda", 0), 0, 1, GradBucketReducer)
     assert w["mode"] == ("hip-graph" if mode == "1" else "eager")
     return w
 

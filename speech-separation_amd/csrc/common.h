@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <mutex>
+#include <map>
+#include <utility>
 
 struct bf16 { unsigned short x; };          // raw bfloat16 storage
 
@@ -160,5 +163,21 @@ __device__ __forceinline__ s16x8_t tr_frag(const bf16* r0, const bf16* r1) {
 extern "C" const char* dtt_last_error();
 void dtt_set_error(const char* fmt, ...);
 #define DTT_CHECK(cond, ...) do { if (!(cond)) { dtt_set_error(__VA_ARGS__); return -1; } } while (0)
+// Dynamic LDS beyond 64 KB needs hipFuncSetAttribute(MaxDynamicSharedMemorySize): once per (kernel, device) and size
+// reached, not per launch -- it is host time on every launch otherwise, and one more runtime call beside whatever
+// other host threads are doing (c10d's watchdog queries events from a thread of its own).
+inline void dtt_want_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> have;
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    int& h = have[std::make_pair(fn, dev)];
+    if (bytes > h) {
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        h = bytes;
+    }
+}
+
 #define DTT_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
     dtt_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); return -2; } } while (0)

@@ -853,8 +853,8 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
         auto kn = conv3x3_c64_kernel<false>;
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM);
-            hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM);
+            dtt_want_lds((const void*)kr, (int)C64_SMEM);
+            dtt_want_lds((const void*)kn, (int)C64_SMEM);
             attr_set = true;
         }
         if (res) hipLaunchKernelGGL(kr, dim3((total + tpw - 1) / tpw), dim3(512), C64_SMEM, ST, p, tpw);
@@ -877,7 +877,7 @@ extern "C" int dtt_conv3x3_s1(const void* x, const void* wp, const float* bias, 
     sm = max(sm, (size_t)4 * 64 * (bn + 4) * 4);             // output staging overlays the operands
     dim3 grid(p.tiles_f * p.tiles_t * (Co / bn), B);
 #define LAUNCH(TT, TN_) do { auto k = conv3x3_s1_kernel<TT, TN_>; \
-        if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        if (sm > 64 * 1024) dtt_want_lds((const void*)k, (int)sm); \
         hipLaunchKernelGGL(k, grid, dim3(256), sm, ST, p); } while (0)
     if (dtype) { if (tn == 2) LAUNCH(bf16, 2); else LAUNCH(bf16, 1); }
     else { if (tn == 2) LAUNCH(float, 2); else LAUNCH(float, 1); }
@@ -925,7 +925,7 @@ int wgrad_launch(const void* dy, const void* x, float* dw, float* ws, int B, int
         dim3 grid(g.nsplit, Co / g.ct, Ci / g.ct);
         if (g.ct == 64) {
             auto k = conv3x3_wgrad_kernel<64>;
-            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            dtt_want_lds((const void*)k, (int)sm);
             hipLaunchKernelGGL(k, grid, dim3(256), sm, ST, p);
         } else {
             p.ws = nullptr;                                 // four waves per element: atomics

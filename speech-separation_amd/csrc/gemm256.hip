@@ -393,8 +393,8 @@ int dtt_gemm256_try(const DttGemm& p, hipStream_t st) {
     const int sm = NST * STAGE_BYTES;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-        hipFuncSetAttribute((const void*)gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        dtt_want_lds((const void*)gemm256_kernel<false>, sm);
+        dtt_want_lds((const void*)gemm256_kernel<true>, sm);
         attr = true;
     }
     const bool kc = p.a_ks == 1 && p.b_ks == 1 && p.b_mode == 0;

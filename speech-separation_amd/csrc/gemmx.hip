@@ -280,7 +280,7 @@ void launch_x(const DttGemm& p, hipStream_t st) {
     static_assert(sm >= WM * WN * 32 * SLAB_W * 4, "the epilogue slabs overlay the stages");
     static bool attr = false;
     auto k = gemmx_kernel<WM, WN, CONV, NST>;
-    if (!attr) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, sm); attr = true; }
+    if (!attr) { dtt_want_lds((const void*)k, sm); attr = true; }
     const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(WM * WN * 64), sm, st, p);
 }

@@ -626,7 +626,7 @@ int launch_fwd(const LstmP& p, int nw, hipStream_t st) {
     DTT_CHECK(sm <= 160 * 1024, "dtt_lstm_fwd: H=%d does not fit LDS in this dtype", p.H);
     const dim3 grid((p.N + p.nb - 1) / p.nb, 2), block(nw * 64);
 #define LAUNCH_NB(NBT_) do { auto k = lstm_fwd_kernel<T, PF, NBT_>; \
-        if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        if (sm > 64 * 1024) dtt_want_lds((const void*)k, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
     if (p.nb == 8) LAUNCH_NB(8); else if (p.nb == 16) LAUNCH_NB(16); else LAUNCH_NB(32);
 #undef LAUNCH_NB
@@ -644,11 +644,11 @@ int launch_bwd(LstmBwdP p, int nw, hipStream_t st) {
     p.kch = kch;
     if (kch == 4) {
         auto k = lstm_bwd_kernel<T, NP, true>;
-        if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (sm > 64 * 1024) dtt_want_lds((const void*)k, (int)sm);
         hipLaunchKernelGGL(k, dim3((p.N + p.nb - 1) / p.nb, 2), dim3(nw * 64), sm, st, p);
     } else {
         auto k = lstm_bwd_kernel<T, NP, false>;
-        if (sm > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (sm > 64 * 1024) dtt_want_lds((const void*)k, (int)sm);
         hipLaunchKernelGGL(k, dim3((p.N + p.nb - 1) / p.nb, 2), dim3(nw * 64), sm, st, p);
     }
     DTT_LAUNCH_CHECK();
@@ -736,7 +736,7 @@ extern "C" int dtt_lstm_bwd_blk(const void* dy, const void* gates_blk, const flo
     LstmBP p{dy, gates_blk, cst_blk, wpt, dG, dbias, N, L, heads, nblk};
     const size_t sm = (size_t)32 * (1024 + 8) * 2 + 32 * (256 + 8) * 2;
     auto k = lstm_bwd_blk_kernel<8>;
-    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    dtt_want_lds((const void*)k, (int)sm);
     hipLaunchKernelGGL(k, dim3(nblk, 2), dim3(512), sm, reinterpret_cast<hipStream_t>(stream), p);
     DTT_LAUNCH_CHECK();
     return 0;

@@ -683,7 +683,7 @@ extern "C" int dtt_lstm_cluster_fwd(const void* xg, const void* whh, void* y, vo
     { const int nw = dtt_lstm_cluster_sync_words(S); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
     const dim3 grid(cluster_grid(2 * S * G)), block(512);
 #define LAUNCH_CF(TT, UTV, WL) do { auto k = lstm_cluster_fwd_kernel<TT, UTV, WL>; \
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        dtt_want_lds((const void*)k, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
     const int KS = H / 16;                                  // k-steps: the window depth AB must divide it
     if (dtype) {
@@ -717,7 +717,7 @@ extern "C" int dtt_lstm_cluster_bwd(const void* dy, const void* gates_blk, const
     { const int nw = dtt_lstm_cluster_sync_words(S); hipLaunchKernelGGL(zero_words_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sync, nw); }
     const dim3 grid(cluster_grid(2 * S * G)), block(512);
 #define LAUNCH_CB(TT, UTV, WL) do { auto k = lstm_cluster_bwd_kernel<TT, UTV, WL>; \
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        dtt_want_lds((const void*)k, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
     const int KS = 4 * H / 16;
     if (dtype) {

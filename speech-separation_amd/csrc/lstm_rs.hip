@@ -991,12 +991,12 @@ extern "C" int dtt_lstm_rs_fwd(const void* xg, const void* whh, void* y, void* g
     const int U = H / G;
     const size_t sm = ((size_t)2 * 32 * (H + 8) + (size_t)32 * (U + 8)) * 2;
 #define LAUNCH_RF(MTV, KSV, DP) do { auto k = lstm_rs_fwd_kernel<MTV, KSV, DP>; \
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        dtt_want_lds((const void*)k, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
     const int tmin = NT / S;                                // the smallest cluster has floor(NT / S) tiles
     DTT_CHECK((int64_t)2 * NT * L * H * 32 * 4 < (1LL << 31), "dtt_lstm_rs_fwd: saved activations exceed 31-bit byte offsets");
 #define LAUNCH_RD(MTV, KSV) do { auto k = lstm_rs_fwd_deep_kernel<MTV, KSV>; \
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        dtt_want_lds((const void*)k, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
     if (H == 512) { if (tmin >= 4) LAUNCH_RD(2, 32); else if (tmin == 3) LAUNCH_RF(2, 32, true); else LAUNCH_RF(2, 32, false); }
     else { if (tmin >= 4) LAUNCH_RD(4, 16); else if (tmin == 3) LAUNCH_RF(4, 16, true); else LAUNCH_RF(4, 16, false); }
@@ -1024,7 +1024,7 @@ extern "C" int dtt_lstm_rs_bwd(const void* dy, const void* gates_blk, const floa
     const int U = H / G, MTB = U / 16;
     const size_t sm = (size_t)4 * MTB * 2 * 64 * 16 + (size_t)32 * (4 * U + 8) * 2 + (size_t)4 * 16 * (H + 8) * 2;
 #define LAUNCH_RB(MTV, KSV, DP) do { auto k = lstm_rs_bwd_kernel<MTV, KSV, DP>; \
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+        dtt_want_lds((const void*)k, (int)sm); \
         hipLaunchKernelGGL(k, grid, block, sm, st, p); } while (0)
     const bool deep = NT / S >= 3;
     if (H == 512) { if (deep) LAUNCH_RB(4, 16, true); else LAUNCH_RB(4, 16, false); }

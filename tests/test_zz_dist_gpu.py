@@ -250,5 +250,5 @@ def test_reducer_async_path_over_rccl_one_rank():
     import subprocess
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_single_rank_probe.py")
     r = subprocess.run([sys.executable, "-u", script], capture_output=True, text=True, timeout=110)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0, r.stdout[-2000:] + "\n---- stderr (head) ----\n" + r.stderr[:3000] + "\n---- stderr (tail) ----\n" + r.stderr[-2000:]
     assert "rccl single-rank probe ok" in r.stdout
